@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""bench.py -- training positions/sec of the NNUE hot path on MI355X.
+
+Workload = BASELINE.json configs[1]: Chess768 -> 1024x2 SCReLU -> 1 with 8 output buckets,
+batch 16384 per GPU, AdamW; one "step" = fwd + bwd (+ gradient all-reduce when N > 1) + AdamW
+over one batch of synthetic positions that is already resident in HBM.
+N > 1: one process per GPU (torchrun), data parallel, gradients all-reduced with RCCL, weak scaling
+(per-GPU batch fixed at 16384, global batch 16384*N, adj = 1/global batch as run.rs:130 does).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
+kernel (timed live with HIP events on the kernels' own stream) and `cpu_baseline` (the CPU oracle,
+scalar single-thread port of the reference semantics, timed on a bounded sample on this host).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+# ----------------------------------------------------------------------------- synthetic positions
+def splitmix64_stream(seed, n):
+    """n outputs of SplitMix64 seeded with `seed` (vectorised: state_i = seed + (i+1)*gamma)."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+FIXTURE_HIST = None
+
+
+def synth_records(count, seed, occupancy="full"):
+    """32-byte bulletformat ChessBoard records: k distinct squares with
+    exactly one own king (code 5) and one opponent king (13), other pieces uniform over the legal
+    non-king codes, score ~ clamp(round(400 N(0,1)), +-2000), result uniform, ksq / opp_ksq derived."""
+    per = 80
+    r = splitmix64_stream(seed, count * per).reshape(count, per)
+    if occupancy == "full":
+        k = np.full(count, 32, dtype=np.int64)
+    else:  # piece-count histogram of examples/tests/batch.bf (mean 16.2), sampled by inverse CDF
+        global FIXTURE_HIST
+        if FIXTURE_HIST is None:
+            rec = np.fromfile(os.path.join(ROOT, "tests", "golden", "batch.bf"), dtype=np.uint8).reshape(-1, 32)
+            occ = rec[:, :8].copy().view(np.uint64).reshape(-1)
+            pop = np.array([bin(int(o)).count("1") for o in occ])
+            FIXTURE_HIST = np.cumsum(np.bincount(pop, minlength=33) / pop.size)
+        u = (r[:, 70] >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+        k = np.clip(np.searchsorted(FIXTURE_HIST, u), 2, 32)
+    # k distinct squares = the k smallest of 64 random keys
+    keys = (r[:, :64] >> np.uint64(8)).astype(np.int64)
+    order = np.argsort(keys, axis=1, kind="stable")                # random permutation of squares
+    rank = np.empty_like(order)
+    np.put_along_axis(rank, order, np.arange(64)[None, :].repeat(count, 0), axis=1)
+    on = rank < k[:, None]                                          # [count][64] occupied squares
+    occ = (on.astype(np.uint64) << np.arange(64, dtype=np.uint64)[None, :]).sum(axis=1, dtype=np.uint64)
+    # piece codes: squares with rank 0 / 1 are the two kings, others uniform over {0..4, 8..12}
+    nonking = np.array([0, 1, 2, 3, 4, 8, 9, 10, 11, 12], dtype=np.uint8)
+    code = nonking[(r[:, :64] & np.uint64(0xFF)).astype(np.int64) % 10]
+    code = np.where(rank == 0, 5, np.where(rank == 1, 13, code)).astype(np.uint8)
+    rec = np.zeros((count, 32), dtype=np.uint8)
+    rec[:, :8] = occ.view(np.uint8).reshape(count, 8)
+    # nibbles in ascending-square order of the occupied squares, low nibble first
+    pos_in_list = np.cumsum(on, axis=1) - 1
+    pcs = np.zeros((count, 16), dtype=np.uint8)
+    rows, sqs = np.nonzero(on)
+    li = pos_in_list[rows, sqs]
+    np.add.at(pcs, (rows, li // 2), (code[rows, sqs].astype(np.uint8) << ((li % 2) * 4).astype(np.uint8)))
+    rec[:, 8:24] = pcs
+    # Box-Muller normal from two uniforms
+    u1 = ((r[:, 64] >> np.uint64(11)).astype(np.float64) + 1.0) / float(1 << 53)
+    u2 = (r[:, 65] >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    nrm = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+    score = np.clip(np.round(400.0 * nrm), -2000, 2000).astype(np.int16)
+    rec[:, 24:26] = score.view(np.uint8).reshape(count, 2)
+    rec[:, 26] = (r[:, 66] % np.uint64(3)).astype(np.uint8)
+    rec[:, 27] = np.argmax(rank == 0, axis=1).astype(np.uint8)          # own king square
+    rec[:, 28] = (np.argmax(rank == 1, axis=1) ^ 56).astype(np.uint8)   # opponent king square ^ 56
+    return rec.reshape(-1)
+
+
+# ----------------------------------------------------------------------------- workload
+CFG2 = dict(num_inputs=768, nnz=32, ft_out=1024, ft_act="screlu", num_buckets=8, dense=[(1, "identity", True)])
+
+
+def algorithmic_bytes(kernel, B, nbar, P=2, H=1024, N=32, F=768, K=2048, O=8):
+    """ALGORITHMIC bytes per launch (stated in DESIGN.md). nbar = mean active features."""
+    ft_fwd = P * B * (nbar * H * 4 + N * 4 + H * 4) + H * 4
+    ft_bwd = P * B * (nbar * H * 4 + 2 * H * 4 + N * 4) + F * H * 4
+    dense_pass = (K + 1) * B * 4 + K * O * 4
+    table = {
+        "ft_fwd_generic": ft_fwd, "ft_fwd_lds": ft_fwd,
+        "ft_bwd_gather": P * B * nbar * H * 4 + F * H * 4,          # the gather-sum part of ft_bwd
+        "ft_bwd_make_g": P * B * 3 * H * 4,                          # dout, out -> g
+        "ft_bwd_lds": ft_bwd, "ft_bwd_merge": 2 * F * H * 4,
+        "ft_index_kernel": P * B * N * 4 + P * B * N * 2,
+        "dense_fwd_kernel": dense_pass, "dense_bwd_dx_kernel": dense_pass, "dense_bwd_dw_kernel": dense_pass,
+        "adamw_kernel": 28 * (F * H + H + K * O + O),
+        "sigmoid_mse_kernel": 5 * B * 4,
+    }
+    return table.get(kernel)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=16384, help="positions per GPU per step")
+    ap.add_argument("--occupancy", choices=["full", "fixture"], default="full",
+                    help="pieces per synthetic position: 32 (worst case) or the batch.bf histogram (mean 16.2)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    args = ap.parse_args()
+
+    import torch
+    from bullet_amd import lib
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+
+    L = lib.load()
+    B = args.batch
+    global_batch = B * world
+    n_distinct = 4  # distinct resident batches, rotated
+    idesc = lib.make_input_desc("chess768")
+    batches, nbar = [], 0.0
+    for i in range(n_distinct):
+        rec = synth_records(B, 0xB011E7000 + 2 + 1000 * (rank * n_distinct + i), args.occupancy)
+        stm, ntm, bk, tg, w = lib.map_batch(idesc, rec, out_buckets=8, blend=0.75, eval_scale=400.0, threads=8)
+        cnt = np.where((stm < 0).any(1), (stm < 0).argmax(1), 32)
+        nbar += cnt.mean() / n_distinct
+        batches.append((stm, ntm, bk, tg, w))
+
+    desc = lib.make_net_desc(**CFG2)
+    net = lib.Net(desc, B)
+    # random-init weights of the architecture: Normal(0, sqrt(2/in)) from a fixed stream, same on all ranks
+    rng = np.random.default_rng(1234)
+    init = []
+    for t, n in enumerate(net.sizes):
+        fan_in = 768 if t == 0 else 2048
+        init.append(np.zeros(n, np.float32) if t & 1 else (rng.standard_normal(n) * np.sqrt(2.0 / fan_in)).astype(np.float32))
+    net.set_params(init)
+    dev_batches = []
+    for stm, ntm, bk, tg, w in batches:
+        t = [torch.from_numpy(a).cuda() for a in (stm, ntm, bk, tg, w)]
+        dev_batches.append(net.make_batch(*t))
+    adj = torch.tensor([1.0 / global_batch], device="cuda")
+    lr = torch.tensor([1e-3], device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        net.forward_backward(dev_batches[i % n_distinct], stream)
+        if dist is not None:
+            dist.all_reduce(net.grads)  # sum over ranks; replicas stay identical
+            dist.all_reduce(net.loss)
+        net.optimiser_step(adj, lr, stream)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    profile = not args.no_profile
+    if profile:
+        lib.profile_start(args.steps * 16 + 64)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kern = lib.profile_stop() if profile else {}
+    loss_per_pos = net.loss.item() / global_batch
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = global_batch * args.steps / elapsed
+        out = {
+            "metric": "training positions/sec (whole node) HalfKA-1024 SCReLU net at 1/2/4/8 GPUs",
+            "value": value, "unit": "positions/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: Chess768 -> 1024x2 SCReLU -> 1, 8 output buckets, AdamW, "
+                                   "fwd+bwd+optimiser step", "batch_per_gpu": B, "global_batch": global_batch,
+                       "occupancy": args.occupancy, "mean_active_features": round(float(nbar), 2),
+                       "parallelism": f"dp{world}"},
+            "final_loss": loss_per_pos,
+        }
+        if kern:
+            per_kernel = {k: {"launches": c, "avg_us": 1e3 * ms / c} for k, (c, ms) in kern.items()}
+            out["kernels_us_per_step"] = {k: round(1e3 * ms / args.steps, 2) for k, (c, ms) in kern.items()}
+            dom = max(kern, key=lambda k: kern[k][1])
+            c, ms = kern[dom]
+            abytes = algorithmic_bytes(dom, B, nbar)
+            launches_per_step = c / args.steps
+            avg_s = ms / c * 1e-3
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # PMC passes, see profiles/README.md
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+            if abytes:
+                per_launch = abytes / max(launches_per_step, 1.0)
+                ach = per_launch / avg_s / 1e9
+                out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                                   "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": per_launch}
+            out["kernel_detail"] = per_kernel
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(batches[0], B)
+        print(json.dumps(out))
+    net.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(batch, B):
+    """The CPU oracle (oracle/, a scalar single-thread port of the reference's CPU semantics: the
+    reference has no CPU backend of its own) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    do = ob.make_net(**CFG2)
+    params = ob.net_init(do)
+    m = [np.zeros_like(p) for p in params]
+    v = [np.zeros_like(p) for p in params]
+    stm, ntm, bk, tg, w = batch
+    sample = min(B, 16384)
+    stm, ntm, bk, tg, w = (np.ascontiguousarray(a[:sample]) for a in (stm, ntm, bk, tg, w))
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        _, grads, _ = ob.net_fwd_bwd(do, params, stm, ntm, bk, tg, w)
+        for p_, m_, v_, g_ in zip(params, m, v, grads):
+            ob.adamw(p_, m_, v_, g_, 1.0 / sample, 1e-3)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or steps >= 8:
+            break
+    return {"value": sample * steps / el, "unit": "positions/sec", "cores": 1, "kind": "port",
+            "sample": f"{steps} full training steps (fwd+bwd+AdamW) of {sample} positions, {el:.1f} s, "
+                      "oracle/bullet_oracle.c -O2 scalar"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,110 @@
+// Shared helpers for libbullet_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/bullet_amd.h"
+
+void bt_set_error(const char *fmt, ...);
+
+#define BT_HIP(call)                                                              \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess) {                                                   \
+            bt_set_error("%s: %s", hipGetErrorName(e_), hipGetErrorString(e_));   \
+            return BT_ERR_HIP;                                                    \
+        }                                                                         \
+    } while (0)
+
+#define BT_REQUIRE(cond, ...)          \
+    do {                               \
+        if (!(cond)) {                 \
+            bt_set_error(__VA_ARGS__); \
+            return BT_ERR_INVALID;     \
+        }                              \
+    } while (0)
+
+#define BT_LAUNCH_CHECK() BT_HIP(hipGetLastError())
+
+static inline hipStream_t bt_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int bt_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline size_t bt_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// ---- per-kernel HIP-event profiler (bt_profile_* in the C ABI) ----
+// Every kernel launch goes through BT_LAUNCH(id, stream, ...): when profiling is on, a pair of events
+// is recorded on the kernel's own stream around the launch; bt_profile_stop() sums the elapsed times.
+enum BtKernelId {
+    BTK_FT_FWD_GENERIC = 0,
+    BTK_FT_FWD_LDS,
+    BTK_FT_INDEX,
+    BTK_FT_BWD_MAKE_G,
+    BTK_FT_BWD_GATHER,
+    BTK_FT_BWD_LDS,
+    BTK_FT_BWD_MERGE,
+    BTK_COLSUM_PARTIAL,
+    BTK_COLSUM_FINAL,
+    BTK_DENSE_FWD,
+    BTK_DENSE_BWD_DX,
+    BTK_DENSE_BWD_DW,
+    BTK_SUM_PARTIALS,
+    BTK_SIGMOID_MSE,
+    BTK_ADAMW,
+    BTK_COUNT
+};
+bool bt_prof_enabled();
+void bt_prof_record(int id, hipStream_t s, bool begin);
+struct BtProfScope {
+    int id;
+    hipStream_t s;
+    bool on;
+    BtProfScope(int id_, hipStream_t s_) : id(id_), s(s_), on(bt_prof_enabled()) {
+        if (on) bt_prof_record(id, s, true);
+    }
+    ~BtProfScope() {
+        if (on) bt_prof_record(id, s, false);
+    }
+};
+#define BT_LAUNCH(id, stream, kernel, grid, block, lds, ...)                        \
+    do {                                                                            \
+        BtProfScope prof_scope_(id, stream);                                        \
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);          \
+    } while (0)
+
+// ---- device-side activation helpers (semantics: dfo.rs:47-103, pointwise.rs:54-139) ----
+__device__ __forceinline__ float bt_act_fwd(int act, float v) {
+    switch (act) {
+    case BT_ACT_RELU: return fmaxf(v, 0.0f);
+    case BT_ACT_CRELU: return fminf(fmaxf(v, 0.0f), 1.0f);
+    case BT_ACT_SCRELU: {
+        float c = fminf(fmaxf(v, 0.0f), 1.0f);
+        return c * c;
+    }
+    case BT_ACT_SQRRELU: {
+        float c = fmaxf(v, 0.0f);
+        return c * c;
+    }
+    default: return v;
+    }
+}
+
+// derivative computed from the activation OUTPUT, composed exactly as dfo.rs does:
+// CReLU' = [o>0]*[1-o>0]; SCReLU' = half+half, half = CReLU'(o)*sqrt(o); SqrReLU' likewise with ReLU'.
+__device__ __forceinline__ float bt_act_deriv(int act, float o) {
+    switch (act) {
+    case BT_ACT_RELU: return o > 0.0f ? 1.0f : 0.0f;
+    case BT_ACT_CRELU: return (o > 0.0f ? 1.0f : 0.0f) * ((1.0f - o) > 0.0f ? 1.0f : 0.0f);
+    case BT_ACT_SCRELU: {
+        float half = ((o > 0.0f ? 1.0f : 0.0f) * ((1.0f - o) > 0.0f ? 1.0f : 0.0f)) * __fsqrt_rn(o);
+        return half + half;
+    }
+    case BT_ACT_SQRRELU: {
+        float half = (o > 0.0f ? 1.0f : 0.0f) * __fsqrt_rn(o);
+        return half + half;
+    }
+    default: return 1.0f;
+    }
+}

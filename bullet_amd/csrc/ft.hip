@@ -1,0 +1,474 @@
+// Sparse feature transformer: forward (gather-sum + bias + activation [+ pairwise]) and
+// backward (sorted-by-feature segmented reduction, no float atomics).
+//
+// Reference semantics: SparseMatmul / SparseMatmulBwdMulti,
+// crates/compiler/src/tensor/operation/linear/sparse.rs:86-119,151-187,253-271, with the device
+// stop-at-first-invalid-index rule of crates/gpu/src/pointwise/write.rs:229-233,300-304.
+//
+// Data layout (all fp32 / int32):
+//   W    [cols][stride]   column-major weights, feature j = contiguous column W[j*stride + offset ...]
+//   idx  [B][nnz]         per input ("perspective"), valid indices first, first invalid index ends the list
+//   out  [B][out_ld]      input k occupies columns [k*out_w, (k+1)*out_w)
+//   saved[n_inputs][B][rows]  (pairwise only) activated halves before the product
+//
+// Entry e = k*B + b enumerates (input, position) pairs.  The backward splits the entries of each input
+// into chunks of FT_CHUNK positions; `ft_index_kernel` builds, per chunk, the list of local entry ids
+// sorted by feature (stable, so ascending entry order inside a feature) plus per-feature offsets.
+// Every dW element is then summed chunk by chunk, entry by entry, in that fixed order: the result is
+// bit-identical run to run (the reference's atomicAdd order is arbitrary).
+#include "common.h"
+
+namespace {
+
+constexpr int FT_CHUNK = 256;  // positions per index chunk (local ids fit u16)
+
+struct float4_t {
+    float x, y, z, w;
+};
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<1> {
+    float v[1];
+};
+template <>
+struct Vec<4> {
+    float v[4];
+};
+
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> vload(const float *p) {
+    Vec<VEC> r;
+    if constexpr (VEC == 4) {
+        float4 t = *reinterpret_cast<const float4 *>(p);
+        r.v[0] = t.x, r.v[1] = t.y, r.v[2] = t.z, r.v[3] = t.w;
+    } else {
+        r.v[0] = *p;
+    }
+    return r;
+}
+
+template <int VEC>
+__device__ __forceinline__ void vstore(float *p, const Vec<VEC> &r) {
+    if constexpr (VEC == 4) {
+        *reinterpret_cast<float4 *>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    } else {
+        *p = r.v[0];
+    }
+}
+
+// ------------------------------------------------------------------ generic forward
+// One thread per (entry, VEC rows) -- any shape.  Used when the LDS-resident path does not apply.
+template <int VEC, bool PAIR>
+__global__ __launch_bounds__(256) void ft_fwd_generic(const float *__restrict__ w, const float *__restrict__ bias,
+                                                      const int32_t *__restrict__ idx0,
+                                                      const int32_t *__restrict__ idx1, float *__restrict__ out,
+                                                      float *__restrict__ saved, bt_ft_desc d) {
+    const int out_w = PAIR ? d.rows / 2 : d.rows;
+    const int groups = out_w / VEC;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)d.n_inputs * d.batch * groups;
+    if (t >= total) return;
+    const int g = (int)(t % groups);
+    const long long e = t / groups;
+    const int k = (int)(e / d.batch);
+    const int b = (int)(e % d.batch);
+    const int32_t *idx = (k == 0 ? idx0 : idx1) + (size_t)b * d.nnz;
+    const int r0 = g * VEC;
+
+    Vec<VEC> a0, a1;
+#pragma unroll
+    for (int q = 0; q < VEC; q++) a0.v[q] = 0.0f, a1.v[q] = 0.0f;
+    for (int i = 0; i < d.nnz; i++) {
+        const int j = idx[i];
+        if (j < 0 || j >= d.cols) break;  // write.rs:231
+        const float *col = w + (size_t)j * d.stride + d.offset + r0;
+        Vec<VEC> x = vload<VEC>(col);
+#pragma unroll
+        for (int q = 0; q < VEC; q++) a0.v[q] += x.v[q];
+        if constexpr (PAIR) {
+            Vec<VEC> y = vload<VEC>(col + out_w);
+#pragma unroll
+            for (int q = 0; q < VEC; q++) a1.v[q] += y.v[q];
+        }
+    }
+    Vec<VEC> o;
+    if constexpr (PAIR) {
+        Vec<VEC> c0, c1;
+#pragma unroll
+        for (int q = 0; q < VEC; q++) {
+            float x0 = a0.v[q] + (bias ? bias[r0 + q] : 0.0f);
+            float x1 = a1.v[q] + (bias ? bias[r0 + out_w + q] : 0.0f);
+            c0.v[q] = bt_act_fwd(d.act, x0);
+            c1.v[q] = bt_act_fwd(d.act, x1);
+            o.v[q] = c0.v[q] * c1.v[q];
+        }
+        float *sv = saved + ((size_t)k * d.batch + b) * d.rows + r0;
+        vstore<VEC>(sv, c0);
+        vstore<VEC>(sv + out_w, c1);
+    } else {
+#pragma unroll
+        for (int q = 0; q < VEC; q++) o.v[q] = bt_act_fwd(d.act, a0.v[q] + (bias ? bias[r0 + q] : 0.0f));
+    }
+    vstore<VEC>(out + (size_t)b * d.out_ld + (size_t)k * out_w + r0, o);
+}
+
+// ------------------------------------------------------------------ index build (shared by all backward paths)
+// One workgroup per chunk.  W waves; wave w owns the contiguous entry sub-range w of the chunk and a
+// private per-feature counter row, so the fill pass is race-free and stable without cross-wave ordering.
+//   pass 0: n_valid per entry (first invalid index ends the list)
+//   pass 1: per-wave histograms (LDS integer atomics: order-independent)
+//   scan  : exclusive scan in (feature major, wave minor) order -> start[w][f]; offs[chunk][f] to global
+//   pass 2: each wave walks its entries in order, 64/nnz_pad entries per step; lanes with equal feature
+//           rank themselves by ballot (one ballot per feature-id bit) and take consecutive slots.
+__global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t *__restrict__ idx1, int batch,
+                                int nnz, int cols, int chunks_per_input, int fbits, uint16_t *__restrict__ sorted,
+                                uint32_t *__restrict__ offs) {
+    extern __shared__ uint32_t lds[];
+    const int nwaves = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    uint32_t *cnt = lds;                       // [nwaves][cols]
+    uint32_t *tsum = lds + (size_t)nwaves * cols;  // [blockDim.x] scan scratch
+
+    const int c = blockIdx.x;
+    const int k = c / chunks_per_input;
+    const int cb = c % chunks_per_input;
+    const int b0 = cb * FT_CHUNK;
+    const int n_e = min(FT_CHUNK, batch - b0);
+    const int32_t *idx = (k == 0 ? idx0 : idx1) + (size_t)b0 * nnz;
+    uint16_t *my_sorted = sorted + (size_t)c * FT_CHUNK * nnz;
+    uint32_t *my_offs = offs + (size_t)c * (cols + 1);
+
+    for (int i = threadIdx.x; i < nwaves * cols; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+
+    // entries per wave-step: 64 / (nnz rounded up to a power of two <= 64)
+    int slot = 1;
+    while (slot < nnz) slot <<= 1;           // host guarantees nnz <= 64
+    const int eps = 64 / slot;                // entries per step
+    const int sub = lane / slot;              // which entry of the step
+    const int li = lane % slot;               // index slot inside the entry
+    const int per_wave = (n_e + nwaves - 1) / nwaves;
+    const int e_lo = wave * per_wave;
+    const int e_hi = min(n_e, e_lo + per_wave);
+
+    // pass 1
+    for (int e = e_lo + sub; e - sub < e_hi; e += eps) {
+        int j = -1;
+        if (e < e_hi && li < nnz) j = idx[(size_t)e * nnz + li];
+        const bool inval = (e < e_hi) && (li >= nnz || j < 0 || j >= cols);
+        // first invalid lane inside this entry's lane segment
+        unsigned long long bal = __ballot(inval);
+        unsigned long long seg = (slot == 64) ? ~0ull : (((1ull << slot) - 1) << (sub * slot));
+        unsigned long long m = bal & seg;
+        int nvalid = m ? (__ffsll((long long)m) - 1 - sub * slot) : slot;
+        if (e < e_hi && li < nvalid) atomicAdd(&cnt[(size_t)wave * cols + j], 1u);
+    }
+    __syncthreads();
+
+    // scan: thread t owns features [t*per, (t+1)*per)
+    {
+        const int per = (cols + blockDim.x - 1) / blockDim.x;
+        const int f_lo = min(cols, (int)threadIdx.x * per), f_hi = min(cols, f_lo + per);
+        uint32_t s = 0;
+        for (int f = f_lo; f < f_hi; f++)
+            for (int w2 = 0; w2 < nwaves; w2++) s += cnt[(size_t)w2 * cols + f];
+        tsum[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {  // <= 256 values
+            uint32_t run = 0;
+            for (int i = 0; i < (int)blockDim.x; i++) {
+                uint32_t v = tsum[i];
+                tsum[i] = run;
+                run += v;
+            }
+            my_offs[cols] = run;
+        }
+        __syncthreads();
+        uint32_t run = tsum[threadIdx.x];
+        for (int f = f_lo; f < f_hi; f++) {
+            my_offs[f] = run;
+            for (int w2 = 0; w2 < nwaves; w2++) {
+                uint32_t v = cnt[(size_t)w2 * cols + f];
+                cnt[(size_t)w2 * cols + f] = run;
+                run += v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // pass 2
+    uint32_t *start = cnt + (size_t)wave * cols;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int e = e_lo + sub; e - sub < e_hi; e += eps) {
+        int j = -1;
+        if (e < e_hi && li < nnz) j = idx[(size_t)e * nnz + li];
+        const bool inval = (e < e_hi) && (li >= nnz || j < 0 || j >= cols);
+        unsigned long long bal = __ballot(inval);
+        unsigned long long seg = (slot == 64) ? ~0ull : (((1ull << slot) - 1) << (sub * slot));
+        unsigned long long m = bal & seg;
+        int nvalid = m ? (__ffsll((long long)m) - 1 - sub * slot) : slot;
+        const bool active = (e < e_hi) && (li < nvalid);
+        // lanes holding the same feature
+        unsigned long long peers = __ballot(active);
+        for (int bit = 0; bit < fbits; bit++) {
+            unsigned long long bb = __ballot(active && ((j >> bit) & 1));
+            peers &= ((j >> bit) & 1) ? bb : ~bb;
+        }
+        if (active) {
+            const int rank = __popcll(peers & lt_mask);
+            const int count = __popcll(peers);
+            const uint32_t base = start[j];
+            my_sorted[base + rank] = (uint16_t)e;
+            if (rank == count - 1) start[j] = base + count;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ generic backward
+// g[k][b][r] = grad_out * f'(out)  (pairwise: product rule first), dfo.rs:30-40, binary.rs:101-123
+template <int VEC, bool PAIR>
+__global__ __launch_bounds__(256) void ft_bwd_make_g(const float *__restrict__ grad_out,
+                                                     const float *__restrict__ out,
+                                                     const float *__restrict__ saved, float *__restrict__ g,
+                                                     bt_ft_desc d) {
+    const int out_w = PAIR ? d.rows / 2 : d.rows;
+    const int groups = out_w / VEC;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)d.n_inputs * d.batch * groups;
+    if (t >= total) return;
+    const int gi = (int)(t % groups);
+    const long long e = t / groups;
+    const int k = (int)(e / d.batch);
+    const int b = (int)(e % d.batch);
+    const int r0 = gi * VEC;
+    const size_t oo = (size_t)b * d.out_ld + (size_t)k * out_w + r0;
+    Vec<VEC> go = vload<VEC>(grad_out + oo);
+    float *gp = g + (size_t)e * d.rows + r0;
+    if constexpr (PAIR) {
+        const float *sv = saved + (size_t)e * d.rows + r0;
+        Vec<VEC> c0 = vload<VEC>(sv), c1 = vload<VEC>(sv + out_w), g0, g1;
+#pragma unroll
+        for (int q = 0; q < VEC; q++) {
+            g0.v[q] = (go.v[q] * c1.v[q]) * bt_act_deriv(d.act, c0.v[q]);
+            g1.v[q] = (go.v[q] * c0.v[q]) * bt_act_deriv(d.act, c1.v[q]);
+        }
+        vstore<VEC>(gp, g0);
+        vstore<VEC>(gp + out_w, g1);
+    } else {
+        Vec<VEC> o = vload<VEC>(out + oo), r;
+#pragma unroll
+        for (int q = 0; q < VEC; q++) r.v[q] = go.v[q] * bt_act_deriv(d.act, o.v[q]);
+        vstore<VEC>(gp, r);
+    }
+}
+
+// One workgroup per feature; threads cover the rows; chunks and entries visited in ascending order.
+template <int VEC>
+__global__ void ft_bwd_gather(const float *__restrict__ g, const uint16_t *__restrict__ sorted,
+                              const uint32_t *__restrict__ offs, float *__restrict__ dw, bt_ft_desc d,
+                              int chunks_per_input) {
+    const int f = blockIdx.x;
+    const int nchunks = d.n_inputs * chunks_per_input;
+    for (int r0 = threadIdx.x * VEC; r0 < d.rows; r0 += blockDim.x * VEC) {
+        Vec<VEC> acc;
+#pragma unroll
+        for (int q = 0; q < VEC; q++) acc.v[q] = 0.0f;
+        for (int c = 0; c < nchunks; c++) {
+            const uint32_t s = offs[(size_t)c * (d.cols + 1) + f];
+            const uint32_t e = offs[(size_t)c * (d.cols + 1) + f + 1];
+            if (s == e) continue;
+            const int k = c / chunks_per_input, cb = c % chunks_per_input;
+            const size_t ebase = (size_t)k * d.batch + (size_t)cb * FT_CHUNK;
+            const uint16_t *lst = sorted + (size_t)c * FT_CHUNK * d.nnz;
+            for (uint32_t q2 = s; q2 < e; q2++) {
+                Vec<VEC> x = vload<VEC>(g + (ebase + lst[q2]) * d.rows + r0);
+#pragma unroll
+                for (int q = 0; q < VEC; q++) acc.v[q] += x.v[q];
+            }
+        }
+        vstore<VEC>(dw + (size_t)f * d.stride + d.offset + r0, acc);
+    }
+}
+
+// deterministic column sums of an [M][C] matrix: pass 1 = sequential sums over row blocks,
+// pass 2 = sequential sum of the partials
+__global__ void colsum_partial(const float *__restrict__ in, int M, int C, int rows_per_block,
+                               float *__restrict__ partial) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    float s = 0.0f;
+    for (int m = m0; m < m1; m++) s += in[(size_t)m * C + c];
+    partial[(size_t)blockIdx.y * C + c] = s;
+}
+
+__global__ void colsum_final(const float *__restrict__ partial, int nblk, int C, float *__restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.0f;
+    for (int i = 0; i < nblk; i++) s += partial[(size_t)i * C + c];
+    out[c] = s;
+}
+
+struct FtPlan {
+    int vec;
+    int chunks_per_input, nchunks;
+    int index_waves;
+    int fbits;
+    size_t off_sorted, off_offs, off_g, off_bpart, total;
+    int bias_blocks;
+};
+
+int ft_validate(const bt_ft_desc *d, const char *who) {
+    BT_REQUIRE(d, "%s: null descriptor", who);
+    BT_REQUIRE(d->batch > 0 && d->rows > 0 && d->cols > 0 && d->nnz > 0, "%s: Mismatched sizes! (non-positive dim)", who);
+    BT_REQUIRE(d->rows + d->offset <= d->stride, "%s: %d + %d > %d", who, d->rows, d->offset, d->stride);  // sparse.rs:30-32
+    BT_REQUIRE(d->n_inputs >= 1 && d->n_inputs <= 2, "%s: n_inputs must be 1 or 2", who);
+    BT_REQUIRE(d->nnz <= 64, "%s: nnz > 64 unsupported", who);
+    BT_REQUIRE(d->act >= BT_ACT_IDENTITY && d->act <= BT_ACT_SQRRELU, "%s: unknown activation", who);
+    BT_REQUIRE(!d->pairwise || d->rows % 2 == 0, "%s: pairwise needs even rows", who);
+    const int out_w = d->pairwise ? d->rows / 2 : d->rows;
+    BT_REQUIRE(d->out_ld >= d->n_inputs * out_w, "%s: Mismatched sizes! (out_ld < n_inputs*out_w)", who);
+    return BT_OK;
+}
+
+int ft_vec(const bt_ft_desc *d) {
+    const int out_w = d->pairwise ? d->rows / 2 : d->rows;
+    return (out_w % 4 == 0 && d->stride % 4 == 0 && d->offset % 4 == 0 && d->out_ld % 4 == 0 && d->rows % 4 == 0) ? 4 : 1;
+}
+
+int ft_plan(const bt_ft_desc *d, FtPlan *p) {
+    p->vec = ft_vec(d);
+    p->chunks_per_input = bt_div_up(d->batch, FT_CHUNK);
+    p->nchunks = p->chunks_per_input * d->n_inputs;
+    // LDS budget for the index kernel: nwaves*cols + 64*nwaves words
+    int wv = 4;
+    while (wv > 1 && ((size_t)wv * d->cols + 64 * wv) * 4 > 150 * 1024) wv >>= 1;
+    BT_REQUIRE(((size_t)wv * d->cols + 64 * wv) * 4 <= 150 * 1024, "bt_ft_backward: cols=%d too large", d->cols);
+    p->index_waves = wv;
+    p->fbits = 1;
+    while ((1 << p->fbits) < d->cols) p->fbits++;
+    size_t o = 0;
+    p->off_sorted = o;
+    o += bt_align((size_t)p->nchunks * FT_CHUNK * d->nnz * sizeof(uint16_t));
+    p->off_offs = o;
+    o += bt_align((size_t)p->nchunks * (d->cols + 1) * sizeof(uint32_t));
+    p->off_g = o;
+    o += bt_align((size_t)d->n_inputs * d->batch * d->rows * sizeof(float));
+    p->bias_blocks = bt_div_up((long long)d->n_inputs * d->batch, 256);
+    p->off_bpart = o;
+    o += bt_align((size_t)p->bias_blocks * d->rows * sizeof(float));
+    p->total = o;
+    return BT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bt_ft_forward(void *stream, const bt_ft_desc *d, const float *w, const float *bias, const int32_t *const *idx,
+                  float *out, float *saved) {
+    if (int rc = ft_validate(d, "bt_ft_forward")) return rc;
+    BT_REQUIRE(w && idx && idx[0] && out, "bt_ft_forward: null pointer");
+    BT_REQUIRE(d->n_inputs == 1 || idx[1], "bt_ft_forward: null index pointer for input 1");
+    BT_REQUIRE(!d->pairwise || saved, "bt_ft_forward: pairwise needs a `saved` buffer");
+    const int vec = ft_vec(d);
+    const int out_w = d->pairwise ? d->rows / 2 : d->rows;
+    const long long total = (long long)d->n_inputs * d->batch * (out_w / vec);
+    dim3 grid(bt_div_up(total, 256)), block(256);
+    hipStream_t s = bt_stream(stream);
+    const int32_t *i0 = idx[0], *i1 = d->n_inputs > 1 ? idx[1] : idx[0];
+    if (vec == 4) {
+        if (d->pairwise)
+            BT_LAUNCH(BTK_FT_FWD_GENERIC, s, (ft_fwd_generic<4, true>), grid, block, 0, w, bias, i0, i1, out, saved, *d);
+        else
+            BT_LAUNCH(BTK_FT_FWD_GENERIC, s, (ft_fwd_generic<4, false>), grid, block, 0, w, bias, i0, i1, out, saved, *d);
+    } else {
+        if (d->pairwise)
+            BT_LAUNCH(BTK_FT_FWD_GENERIC, s, (ft_fwd_generic<1, true>), grid, block, 0, w, bias, i0, i1, out, saved, *d);
+        else
+            BT_LAUNCH(BTK_FT_FWD_GENERIC, s, (ft_fwd_generic<1, false>), grid, block, 0, w, bias, i0, i1, out, saved, *d);
+    }
+    BT_LAUNCH_CHECK();
+    return BT_OK;
+}
+
+size_t bt_ft_backward_workspace_bytes(const bt_ft_desc *d) {
+    if (ft_validate(d, "bt_ft_backward_workspace_bytes")) return 0;
+    FtPlan p;
+    if (ft_plan(d, &p)) return 0;
+    return p.total;
+}
+
+int bt_ft_backward(void *stream, const bt_ft_desc *d, const int32_t *const *idx, const float *grad_out,
+                   const float *out, const float *saved, float *dw, float *dbias, void *workspace,
+                   size_t workspace_bytes) {
+    if (int rc = ft_validate(d, "bt_ft_backward")) return rc;
+    BT_REQUIRE(idx && idx[0] && grad_out && dw && workspace, "bt_ft_backward: null pointer");
+    BT_REQUIRE(d->n_inputs == 1 || idx[1], "bt_ft_backward: null index pointer for input 1");
+    BT_REQUIRE(d->pairwise ? (saved != nullptr) : (out != nullptr), "bt_ft_backward: missing forward activations");
+    FtPlan p;
+    if (int rc = ft_plan(d, &p)) return rc;
+    BT_REQUIRE(workspace_bytes >= p.total, "bt_ft_backward: workspace too small (%zu < %zu)", workspace_bytes, p.total);
+    hipStream_t s = bt_stream(stream);
+    char *ws = static_cast<char *>(workspace);
+    uint16_t *sorted = reinterpret_cast<uint16_t *>(ws + p.off_sorted);
+    uint32_t *offs = reinterpret_cast<uint32_t *>(ws + p.off_offs);
+    float *g = reinterpret_cast<float *>(ws + p.off_g);
+    float *bpart = reinterpret_cast<float *>(ws + p.off_bpart);
+    const int32_t *i0 = idx[0], *i1 = d->n_inputs > 1 ? idx[1] : idx[0];
+
+    {
+        const int threads = p.index_waves * 64;
+        const size_t lds = ((size_t)p.index_waves * d->cols + threads) * sizeof(uint32_t);
+        BT_LAUNCH(BTK_FT_INDEX, s, ft_index_kernel, dim3(p.nchunks), dim3(threads), lds, i0, i1, d->batch, d->nnz, d->cols,
+                           p.chunks_per_input, p.fbits, sorted, offs);
+        BT_LAUNCH_CHECK();
+    }
+    {
+        const int out_w = d->pairwise ? d->rows / 2 : d->rows;
+        const long long total = (long long)d->n_inputs * d->batch * (out_w / p.vec);
+        dim3 grid(bt_div_up(total, 256)), block(256);
+        if (p.vec == 4) {
+            if (d->pairwise)
+                BT_LAUNCH(BTK_FT_BWD_MAKE_G, s, (ft_bwd_make_g<4, true>), grid, block, 0, grad_out, out, saved, g, *d);
+            else
+                BT_LAUNCH(BTK_FT_BWD_MAKE_G, s, (ft_bwd_make_g<4, false>), grid, block, 0, grad_out, out, saved, g, *d);
+        } else {
+            if (d->pairwise)
+                BT_LAUNCH(BTK_FT_BWD_MAKE_G, s, (ft_bwd_make_g<1, true>), grid, block, 0, grad_out, out, saved, g, *d);
+            else
+                BT_LAUNCH(BTK_FT_BWD_MAKE_G, s, (ft_bwd_make_g<1, false>), grid, block, 0, grad_out, out, saved, g, *d);
+        }
+        BT_LAUNCH_CHECK();
+    }
+    if (d->rows != d->stride)  // rows outside [offset, offset+rows) of each column stay zero (sparse.rs:168-170)
+        BT_HIP(hipMemsetAsync(dw, 0, (size_t)d->stride * d->cols * sizeof(float), s));
+    {
+        int threads = bt_div_up(d->rows, p.vec);
+        threads = ((threads + 63) / 64) * 64;
+        if (threads > 256) threads = 256;
+        if (p.vec == 4)
+            BT_LAUNCH(BTK_FT_BWD_GATHER, s, (ft_bwd_gather<4>), dim3(d->cols), dim3(threads), 0, g, sorted, offs, dw, *d,
+                               p.chunks_per_input);
+        else
+            BT_LAUNCH(BTK_FT_BWD_GATHER, s, (ft_bwd_gather<1>), dim3(d->cols), dim3(threads), 0, g, sorted, offs, dw, *d,
+                               p.chunks_per_input);
+        BT_LAUNCH_CHECK();
+    }
+    if (dbias) {
+        const int M = d->n_inputs * d->batch;
+        dim3 grid(bt_div_up(d->rows, 64), p.bias_blocks), block(64);
+        BT_LAUNCH(BTK_COLSUM_PARTIAL, s, colsum_partial, grid, block, 0, g, M, d->rows, 256, bpart);
+        BT_LAUNCH_CHECK();
+        BT_LAUNCH(BTK_COLSUM_FINAL, s, colsum_final, dim3(bt_div_up(d->rows, 64)), dim3(64), 0, bpart, p.bias_blocks, d->rows,
+                           dbias);
+        BT_LAUNCH_CHECK();
+    }
+    return BT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,209 @@
+// Host batch preparation: 32-byte position records -> the five device batch tensors.
+// Mirrors SparseInputType::map_features (crates/bullet_lib/src/game/inputs/{chess768,chess_buckets,
+// ataxx147,factorised}.rs), OutputBuckets::bucket (game/outputs.rs:24-31) and the make_mapper closure
+// (crates/bullet_lib/src/value.rs:77-117), fanned out over worker threads like
+// ModelInputsMapper::map (crates/trainer/src/model/inputs.rs:86-109).  Integer outputs must be bit-exact.
+#include <cmath>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct ChessRecord {  // bulletformat ChessBoard; layout as examples/tests/test4.rs:8-18
+    uint64_t occ;
+    uint8_t pcs[16];
+    int16_t score;
+    uint8_t result, ksq, opp_ksq, extra[3];
+};
+struct AtaxxRecord {  // bulletformat AtaxxBoard; layout as examples/ataxx.rs:8-18
+    uint64_t bbs[3];
+    int16_t score;
+    uint8_t result, origstm;
+    uint16_t fullm;
+    uint8_t halfm, extra;
+};
+static_assert(sizeof(ChessRecord) == 32 && sizeof(AtaxxRecord) == 32, "records are 32 bytes");
+
+inline bool is_ataxx(const bt_input_desc *d) { return d->kind == BT_INPUT_ATAXX147 || d->kind == BT_INPUT_ATAXX98; }
+
+inline float sigmoidf_host(float x) { return 1.0f / (1.0f + std::exp(-x)); }  // value.rs:66-68
+
+// returns the number of features written
+inline int map_one(const bt_input_desc *d, const uint8_t *rec, int32_t *stm, int32_t *ntm) {
+    int cnt = 0;
+    if (is_ataxx(d)) {
+        AtaxxRecord r;
+        std::memcpy(&r, rec, 32);
+        for (int pc = 0; pc < 3; pc++) {
+            for (uint64_t bb = r.bbs[pc]; bb; bb &= bb - 1) {
+                const int sq = __builtin_ctzll(bb);
+                const int s = 49 * pc + sq;
+                if (d->kind == BT_INPUT_ATAXX98 && s >= 98) continue;
+                stm[cnt] = s;
+                ntm[cnt] = (pc == 2) ? s : 49 * (1 - pc) + sq;
+                cnt++;
+            }
+        }
+        return cnt;
+    }
+    ChessRecord r;
+    std::memcpy(&r, rec, 32);
+    int s_flip = 0, n_flip = 0, s_base = 0, n_base = 0;
+    if (d->kind != BT_INPUT_CHESS768) {
+        s_base = 768 * d->buckets[r.ksq];
+        n_base = 768 * d->buckets[r.opp_ksq];
+        if (d->kind == BT_INPUT_CHESS_BUCKETS_MIRRORED) {
+            s_flip = (r.ksq & 7) > 3 ? 7 : 0;
+            n_flip = (r.opp_ksq & 7) > 3 ? 7 : 0;
+        }
+    }
+    const int shift = d->factorised ? 768 : 0;
+    int piece_no = 0;
+    for (uint64_t occ = r.occ; occ; occ &= occ - 1, piece_no++) {
+        const int sq = __builtin_ctzll(occ);
+        const int nib = (r.pcs[piece_no >> 1] >> ((piece_no & 1) * 4)) & 15;
+        const int side = nib >> 3, type_off = (nib & 7) << 6;
+        const int s = s_base + ((side * 384 + type_off + sq) ^ s_flip);
+        const int n = n_base + (((1 - side) * 384 + type_off + (sq ^ 56)) ^ n_flip);
+        stm[cnt] = shift + s;
+        ntm[cnt] = shift + n;
+        cnt++;
+        if (d->factorised) {
+            stm[cnt] = s % 768;
+            ntm[cnt] = n % 768;
+            cnt++;
+        }
+    }
+    return cnt;
+}
+
+void map_range(const bt_input_desc *d, const bt_map_opts *o, const uint8_t *records, int lo, int hi, int nnz,
+               int32_t *stm, int32_t *ntm, int32_t *buckets, float *targets, float *weights) {
+    const float rscale = 1.0f / o->eval_scale;
+    const bool ataxx = is_ataxx(d);
+    for (int k = lo; k < hi; k++) {
+        const uint8_t *rec = records + (size_t)k * 32;
+        int32_t *s = stm + (size_t)k * nnz, *n = ntm + (size_t)k * nnz;
+        const int cnt = map_one(d, rec, s, n);
+        if (cnt < nnz) s[cnt] = n[cnt] = -1;
+        int16_t score_i;
+        uint8_t result;
+        uint64_t occ = 0;
+        if (ataxx) {
+            AtaxxRecord r;
+            std::memcpy(&r, rec, 32);
+            score_i = r.score, result = r.result;
+        } else {
+            ChessRecord r;
+            std::memcpy(&r, rec, 32);
+            score_i = r.score, result = r.result, occ = r.occ;
+        }
+        int bucket = 0;
+        if (o->out_buckets > 1 && !ataxx) {
+            const int divisor = (32 + o->out_buckets - 1) / o->out_buckets;
+            bucket = (uint8_t)((uint8_t)__builtin_popcountll(occ) - 2) / (uint8_t)divisor;
+        }
+        buckets[k] = bucket;
+        weights[k] = 1.0f;
+        if (o->wdl_output) {
+            targets[3 * (size_t)k] = targets[3 * (size_t)k + 1] = targets[3 * (size_t)k + 2] = 0.0f;
+            targets[3 * (size_t)k + result] = 1.0f;
+        } else {
+            float score = (float)score_i;
+            if (o->use_win_rate_model) {
+                const float p = (score - 270.0f) / 380.0f, pm = (-score - 270.0f) / 380.0f;
+                score = 0.5f * (1.0f + sigmoidf_host(p) - sigmoidf_host(pm));
+            } else {
+                score = sigmoidf_host(rscale * score);
+            }
+            const float res = (float)result / 2.0f;
+            targets[k] = o->blend * res + (1.0f - o->blend) * score;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bt_input_init(bt_input_desc *d, int kind, int factorised, const int *layout, int layout_len) {
+    BT_REQUIRE(d, "bt_input_init: null descriptor");
+    BT_REQUIRE(kind >= BT_INPUT_CHESS768 && kind <= BT_INPUT_ATAXX98, "bt_input_init: unknown input kind %d", kind);
+    std::memset(d, 0, sizeof(*d));
+    d->kind = kind;
+    d->num_buckets = 1;
+    const bool ataxx = (kind == BT_INPUT_ATAXX147 || kind == BT_INPUT_ATAXX98);
+    BT_REQUIRE(!(factorised && ataxx), "bt_input_init: factoriser is defined for chess inputs only");
+    d->factorised = factorised ? 1 : 0;
+    if (kind == BT_INPUT_CHESS_BUCKETS) {
+        BT_REQUIRE(layout && layout_len == 64, "bt_input_init: ChessBuckets needs a 64-entry layout");
+        int mx = 0;
+        for (int i = 0; i < 64; i++) {
+            BT_REQUIRE(layout[i] >= 0, "bt_input_init: negative bucket");
+            d->buckets[i] = layout[i];
+            if (layout[i] > mx) mx = layout[i];
+        }
+        d->num_buckets = mx + 1;
+    } else if (kind == BT_INPUT_CHESS_BUCKETS_MIRRORED) {
+        BT_REQUIRE(layout && layout_len == 32, "bt_input_init: ChessBucketsMirrored needs a 32-entry layout");
+        static const int mirror[8] = {0, 1, 2, 3, 3, 2, 1, 0};
+        int mx = 0;
+        for (int i = 0; i < 32; i++) {
+            BT_REQUIRE(layout[i] >= 0, "bt_input_init: negative bucket");
+            if (layout[i] > mx) mx = layout[i];
+        }
+        for (int sq = 0; sq < 64; sq++) d->buckets[sq] = layout[(sq >> 3) * 4 + mirror[sq & 7]];
+        d->num_buckets = mx + 1;
+    }
+    return BT_OK;
+}
+
+int bt_input_num_inputs(const bt_input_desc *d) {
+    if (!d) return 0;
+    int base = 768;
+    switch (d->kind) {
+    case BT_INPUT_CHESS768: base = 768; break;
+    case BT_INPUT_CHESS_BUCKETS:
+    case BT_INPUT_CHESS_BUCKETS_MIRRORED: base = 768 * d->num_buckets; break;
+    case BT_INPUT_ATAXX147: base = 147; break;
+    case BT_INPUT_ATAXX98: base = 98; break;
+    }
+    return base + (d->factorised ? 768 : 0);
+}
+
+int bt_input_max_active(const bt_input_desc *d) {
+    if (!d) return 0;
+    const int m = (d->kind == BT_INPUT_ATAXX147 || d->kind == BT_INPUT_ATAXX98) ? 49 : 32;
+    return d->factorised ? 2 * m : m;
+}
+
+int bt_map_batch(const bt_input_desc *d, const bt_map_opts *o, const void *records, int count, int32_t *stm,
+                 int32_t *nstm, int32_t *buckets, float *targets, float *weights) {
+    BT_REQUIRE(d && o && records && stm && nstm && buckets && targets && weights, "bt_map_batch: null argument");
+    BT_REQUIRE(count >= 0, "bt_map_batch: negative count");
+    // value.rs:114: assert!((0.0..=1.0).contains(&blend))
+    BT_REQUIRE(o->wdl_output || (o->blend >= 0.0f && o->blend <= 1.0f), "WDL proportion must be in [0, 1]");
+    const int nnz = bt_input_max_active(d);
+    int threads = o->threads < 1 ? 1 : o->threads;
+    if (threads > count) threads = count > 0 ? count : 1;
+    const uint8_t *rec = static_cast<const uint8_t *>(records);
+    if (threads == 1) {
+        map_range(d, o, rec, 0, count, nnz, stm, nstm, buckets, targets, weights);
+        return BT_OK;
+    }
+    // chunks of ceil(count/threads), model/inputs.rs:88-103
+    const int chunk = (count + threads - 1) / threads;
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++) {
+        const int lo = t * chunk, hi = std::min(count, lo + chunk);
+        if (lo >= hi) break;
+        pool.emplace_back(map_range, d, o, rec, lo, hi, nnz, stm, nstm, buckets, targets, weights);
+    }
+    for (auto &th : pool) th.join();
+    return BT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,250 @@
+// The lowered training step of the ValueTrainerBuilder net family as one object:
+// what `Function::execute(backwards)` + `Optimiser::update` do per batch in
+// crates/trainer/src/run.rs:185-192, with the op schedule of SURVEY.md section 3.2 hard-wired
+// (FT fwd x perspectives -> dense stack with bucket select -> sigmoid-MSE -> dense bwd -> FT bwd -> AdamW).
+// All buffers are allocated once in bt_net_create (Function::prealloc, function.rs:180-196);
+// a step only enqueues kernels on the caller's stream -- no host sync, no allocation.
+#include <vector>
+
+#include "common.h"
+
+struct bt_net {
+    bt_net_desc d;
+    int max_batch;
+    int n_tensors;
+    size_t n_params;
+    std::vector<size_t> t_off, t_size;
+    float *params = nullptr, *grads = nullptr, *mom = nullptr, *vel = nullptr;
+    bool own_params = false, own_grads = false;
+    bt_adamw_tensor adam[BT_ADAMW_MAX_TENSORS];
+    // activations
+    float *hid = nullptr, *saved = nullptr, *g_hid = nullptr, *grad_y = nullptr;
+    float *a[BT_MAX_DENSE] = {nullptr}, *ga[BT_MAX_DENSE] = {nullptr};
+    void *ft_ws = nullptr, *dense_ws = nullptr;
+    size_t ft_ws_bytes = 0, dense_ws_bytes = 0;
+};
+
+namespace {
+
+int net_validate(const bt_net_desc *d) {
+    BT_REQUIRE(d, "bt_net: null descriptor");
+    BT_REQUIRE(d->num_inputs > 0 && d->nnz > 0 && d->ft_out > 0, "bt_net: Mismatched sizes! (FT dims)");
+    BT_REQUIRE(d->perspectives == 1 || d->perspectives == 2, "bt_net: perspectives must be 1 or 2");
+    BT_REQUIRE(d->n_dense >= 1 && d->n_dense <= BT_MAX_DENSE, "bt_net: n_dense out of range");
+    BT_REQUIRE(d->num_buckets >= 1, "bt_net: num_buckets must be >= 1");
+    BT_REQUIRE(!d->pairwise || d->ft_out % 2 == 0, "bt_net: pairwise needs even ft_out");
+    BT_REQUIRE(d->dense_out[d->n_dense - 1] == 1, "bt_net: last layer must have one output per bucket");
+    BT_REQUIRE(2 + 2 * d->n_dense <= BT_ADAMW_MAX_TENSORS, "bt_net: too many tensors");
+    return BT_OK;
+}
+
+int dense_in(const bt_net_desc *d, int k) {
+    if (k == 0) return d->perspectives * (d->pairwise ? d->ft_out / 2 : d->ft_out);
+    return d->dense_out[k - 1];
+}
+int dense_rows(const bt_net_desc *d, int k) { return d->dense_out[k] * (d->dense_bucketed[k] ? d->num_buckets : 1); }
+
+bt_ft_desc ft_desc(const bt_net *n, int batch) {
+    const bt_net_desc &d = n->d;
+    bt_ft_desc f;
+    f.batch = batch, f.rows = d.ft_out, f.cols = d.num_inputs, f.stride = d.ft_out, f.offset = 0, f.nnz = d.nnz;
+    f.act = d.ft_act, f.pairwise = d.pairwise, f.n_inputs = d.perspectives;
+    f.out_ld = dense_in(&d, 0);
+    return f;
+}
+bt_dense_desc dn_desc(const bt_net *n, int k, int batch) {
+    const bt_net_desc &d = n->d;
+    bt_dense_desc q;
+    q.batch = batch, q.in = dense_in(&d, k), q.out = d.dense_out[k];
+    q.buckets = d.dense_bucketed[k] ? d.num_buckets : 1, q.act = d.dense_act[k];
+    return q;
+}
+
+int dmalloc(float **p, size_t floats) {
+    void *v = nullptr;
+    if (int rc = bt_malloc(&v, floats * sizeof(float))) return rc;
+    *p = static_cast<float *>(v);
+    return BT_OK;
+}
+
+int check_batch(const bt_net *net, const bt_batch *b, const char *who) {
+    BT_REQUIRE(net && b, "%s: null argument", who);
+    BT_REQUIRE(b->batch > 0 && b->batch <= net->max_batch, "%s: Mismatched sizes! (batch %d, max %d)", who, b->batch,
+               net->max_batch);
+    BT_REQUIRE(b->stm && b->targets, "%s: null batch tensor", who);
+    BT_REQUIRE(net->d.perspectives == 1 || b->nstm, "%s: dual-perspective net needs nstm", who);
+    BT_REQUIRE(net->d.num_buckets == 1 || b->buckets, "%s: bucketed net needs bucket indices", who);
+    BT_REQUIRE(!net->d.use_entry_weights || b->entry_weights, "%s: net needs entry_weights", who);
+    return BT_OK;
+}
+
+int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b) {
+    bt_ft_desc f = ft_desc(n, b->batch);
+    const int32_t *idx[2] = {b->stm, b->nstm};
+    if (int rc = bt_ft_forward(s, &f, n->params + n->t_off[0], n->params + n->t_off[1], idx, n->hid, n->saved)) return rc;
+    const float *x = n->hid;
+    for (int k = 0; k < n->d.n_dense; k++) {
+        bt_dense_desc q = dn_desc(n, k, b->batch);
+        if (int rc = bt_dense_forward(s, &q, n->params + n->t_off[2 + 2 * k], n->params + n->t_off[3 + 2 * k], x,
+                                      b->buckets, n->a[k]))
+            return rc;
+        x = n->a[k];
+    }
+    return BT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bt_net_num_tensors(const bt_net_desc *d) { return d ? 2 + 2 * d->n_dense : 0; }
+
+size_t bt_net_tensor_size(const bt_net_desc *d, int t) {
+    if (!d || t < 0 || t >= 2 + 2 * d->n_dense) return 0;
+    if (t == 0) return (size_t)d->ft_out * d->num_inputs;
+    if (t == 1) return (size_t)d->ft_out;
+    const int k = (t - 2) / 2;
+    if ((t & 1) == 0) return (size_t)dense_rows(d, k) * dense_in(d, k);
+    return (size_t)dense_rows(d, k);
+}
+
+size_t bt_net_tensor_offset(const bt_net_desc *d, int t) {
+    size_t off = 0;
+    for (int i = 0; i < t && i < bt_net_num_tensors(d); i++) off += (bt_net_tensor_size(d, i) + 3) / 4 * 4;
+    return off;
+}
+
+size_t bt_net_param_count(const bt_net_desc *d) {
+    size_t n = 0;
+    for (int t = 0; t < bt_net_num_tensors(d); t++) n += (bt_net_tensor_size(d, t) + 3) / 4 * 4;  // 16-B aligned tensors
+    return n;
+}
+
+int bt_net_create(const bt_net_desc *desc, int max_batch, float *ext_params, float *ext_grads, bt_net **out) {
+    if (int rc = net_validate(desc)) return rc;
+    BT_REQUIRE(max_batch > 0 && out, "bt_net_create: bad arguments");
+    bt_net *n = new bt_net();
+    n->d = *desc;
+    n->max_batch = max_batch;
+    n->n_tensors = bt_net_num_tensors(desc);
+    size_t off = 0;
+    for (int t = 0; t < n->n_tensors; t++) {
+        n->t_off.push_back(off);
+        n->t_size.push_back(bt_net_tensor_size(desc, t));
+        off += (n->t_size[t] + 3) / 4 * 4;
+    }
+    n->n_params = off;
+    int rc = BT_OK;
+    auto fail = [&](int code) {
+        bt_net_destroy(n);
+        return code;
+    };
+    if (ext_params) n->params = ext_params;
+    else {
+        if ((rc = dmalloc(&n->params, off))) return fail(rc);
+        n->own_params = true;
+    }
+    if (ext_grads) n->grads = ext_grads;
+    else {
+        if ((rc = dmalloc(&n->grads, off))) return fail(rc);
+        n->own_grads = true;
+    }
+    if ((rc = dmalloc(&n->mom, off))) return fail(rc);
+    if ((rc = dmalloc(&n->vel, off))) return fail(rc);
+    for (int t = 0; t < n->n_tensors; t++) {
+        bt_adamw_tensor &a = n->adam[t];
+        a.grad = n->grads + n->t_off[t], a.param = n->params + n->t_off[t];
+        a.momentum = n->mom + n->t_off[t], a.velocity = n->vel + n->t_off[t];
+        a.n = n->t_size[t];
+        a.decay = 0.01f, a.beta1 = 0.9f, a.beta2 = 0.999f, a.min_weight = -1.98f, a.max_weight = 1.98f;  // adam.rs:29-33
+    }
+    const size_t B = (size_t)max_batch;
+    const int K0 = dense_in(desc, 0);
+    if ((rc = dmalloc(&n->hid, B * K0))) return fail(rc);
+    if ((rc = dmalloc(&n->g_hid, B * K0))) return fail(rc);
+    if (desc->pairwise && (rc = dmalloc(&n->saved, B * desc->perspectives * desc->ft_out))) return fail(rc);
+    if ((rc = dmalloc(&n->grad_y, B))) return fail(rc);
+    for (int k = 0; k < desc->n_dense; k++) {
+        if ((rc = dmalloc(&n->a[k], B * desc->dense_out[k]))) return fail(rc);
+        if ((rc = dmalloc(&n->ga[k], B * desc->dense_out[k]))) return fail(rc);
+        bt_dense_desc q = dn_desc(n, k, max_batch);
+        size_t wsb = bt_dense_backward_workspace_bytes(&q);
+        if (wsb == 0) return fail(BT_ERR_INVALID);
+        if (wsb > n->dense_ws_bytes) n->dense_ws_bytes = wsb;
+    }
+    bt_ft_desc f = ft_desc(n, max_batch);
+    n->ft_ws_bytes = bt_ft_backward_workspace_bytes(&f);
+    if (n->ft_ws_bytes == 0) return fail(BT_ERR_INVALID);
+    if ((rc = bt_malloc(&n->ft_ws, n->ft_ws_bytes))) return fail(rc);
+    if ((rc = bt_malloc(&n->dense_ws, n->dense_ws_bytes))) return fail(rc);
+    *out = n;
+    return BT_OK;
+}
+
+int bt_net_destroy(bt_net *n) {
+    if (!n) return BT_OK;
+    if (n->own_params) bt_free(n->params);
+    if (n->own_grads) bt_free(n->grads);
+    bt_free(n->mom), bt_free(n->vel), bt_free(n->hid), bt_free(n->g_hid), bt_free(n->saved), bt_free(n->grad_y);
+    for (int k = 0; k < BT_MAX_DENSE; k++) bt_free(n->a[k]), bt_free(n->ga[k]);
+    bt_free(n->ft_ws), bt_free(n->dense_ws);
+    delete n;
+    return BT_OK;
+}
+
+float *bt_net_params(bt_net *n) { return n ? n->params : nullptr; }
+float *bt_net_grads(bt_net *n) { return n ? n->grads : nullptr; }
+float *bt_net_momentum(bt_net *n) { return n ? n->mom : nullptr; }
+float *bt_net_velocity(bt_net *n) { return n ? n->vel : nullptr; }
+
+int bt_net_set_adamw(bt_net *n, int t, float decay, float beta1, float beta2, float min_w, float max_w) {
+    BT_REQUIRE(n && t >= 0 && t < n->n_tensors, "bt_net_set_adamw: bad tensor index");
+    BT_REQUIRE(max_w >= min_w, "Invalid clipping: %g >= %g", min_w, max_w);  // adam.rs:259-263
+    bt_adamw_tensor &a = n->adam[t];
+    a.decay = decay, a.beta1 = beta1, a.beta2 = beta2, a.min_weight = min_w, a.max_weight = max_w;
+    return BT_OK;
+}
+
+int bt_net_forward(bt_net *n, void *stream, const bt_batch *b, float *out_dev, float *loss_sum_dev) {
+    if (int rc = check_batch(n, b, "bt_net_forward")) return rc;
+    hipStream_t s = bt_stream(stream);
+    if (int rc = forward_impl(n, s, b)) return rc;
+    const float *y = n->a[n->d.n_dense - 1];
+    if (out_dev) BT_HIP(hipMemcpyAsync(out_dev, y, sizeof(float) * b->batch, hipMemcpyDeviceToDevice, s));
+    if (loss_sum_dev)
+        return bt_sigmoid_mse(s, b->batch, y, b->targets, n->d.use_entry_weights ? b->entry_weights : nullptr,
+                              loss_sum_dev, n->grad_y);
+    return BT_OK;
+}
+
+int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *loss_sum_dev) {
+    if (int rc = check_batch(n, b, "bt_net_forward_backward")) return rc;
+    BT_REQUIRE(loss_sum_dev, "bt_net_forward_backward: null loss buffer");
+    hipStream_t s = bt_stream(stream);
+    if (int rc = forward_impl(n, s, b)) return rc;
+    const int L = n->d.n_dense;
+    if (int rc = bt_sigmoid_mse(s, b->batch, n->a[L - 1], b->targets,
+                                n->d.use_entry_weights ? b->entry_weights : nullptr, loss_sum_dev, n->grad_y))
+        return rc;
+    for (int k = L - 1; k >= 0; k--) {
+        bt_dense_desc q = dn_desc(n, k, b->batch);
+        const float *x = (k == 0) ? n->hid : n->a[k - 1];
+        const float *gy = (k == L - 1) ? n->grad_y : n->ga[k];
+        float *gx = (k == 0) ? n->g_hid : n->ga[k - 1];
+        if (int rc = bt_dense_backward(s, &q, n->params + n->t_off[2 + 2 * k], x, b->buckets, n->a[k], gy,
+                                       n->grads + n->t_off[2 + 2 * k], n->grads + n->t_off[3 + 2 * k], gx, n->dense_ws,
+                                       n->dense_ws_bytes))
+            return rc;
+    }
+    bt_ft_desc f = ft_desc(n, b->batch);
+    const int32_t *idx[2] = {b->stm, b->nstm};
+    return bt_ft_backward(s, &f, idx, n->g_hid, n->hid, n->saved, n->grads + n->t_off[0], n->grads + n->t_off[1],
+                          n->ft_ws, n->ft_ws_bytes);
+}
+
+int bt_net_optimiser_step(bt_net *n, void *stream, const float *adj_dev, const float *lr_dev) {
+    BT_REQUIRE(n, "bt_net_optimiser_step: null net");
+    return bt_adamw(stream, n->n_tensors, n->adam, adj_dev, lr_dev);
+}
+
+}  // extern "C"

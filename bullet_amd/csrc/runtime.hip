@@ -1,0 +1,211 @@
+// Runtime primitives of the C ABI (section 1 of include/bullet_amd.h): the memory / stream
+// half of the reference's GpuBindings trait (crates/gpu/src/runtime/bindings.rs:76-125,
+// ROCm implementation crates/gpu/src/runtime/rocm.rs:66-171), straight on the HIP runtime.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+static thread_local std::string g_last_error;
+
+void bt_set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+namespace {
+struct ProfRec {
+    int id;
+    hipEvent_t a, b;
+};
+struct Profiler {
+    bool on = false;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    std::vector<ProfRec> recs;
+    hipEvent_t pending = nullptr;
+};
+thread_local Profiler g_prof;
+const char *const kKernelNames[BTK_COUNT] = {
+    "ft_fwd_generic", "ft_fwd_lds", "ft_index_kernel", "ft_bwd_make_g", "ft_bwd_gather", "ft_bwd_lds",
+    "ft_bwd_merge", "colsum_partial", "colsum_final", "dense_fwd_kernel", "dense_bwd_dx_kernel",
+    "dense_bwd_dw_kernel", "sum_partials_kernel", "sigmoid_mse_kernel", "adamw_kernel"};
+}  // namespace
+
+bool bt_prof_enabled() { return g_prof.on; }
+
+void bt_prof_record(int id, hipStream_t s, bool begin) {
+    Profiler &p = g_prof;
+    if (p.used >= p.pool.size()) {  // pool exhausted: stop recording rather than allocate mid-run
+        if (begin) p.pending = nullptr;
+        return;
+    }
+    hipEvent_t e = p.pool[p.used++];
+    (void)hipEventRecord(e, s);
+    if (begin) p.pending = e;
+    else if (p.pending) {
+        p.recs.push_back({id, p.pending, e});
+        p.pending = nullptr;
+    }
+}
+
+extern "C" {
+
+int bt_profile_start(int max_launches) {
+    BT_REQUIRE(max_launches > 0, "bt_profile_start: max_launches must be positive");
+    Profiler &p = g_prof;
+    while (p.pool.size() < (size_t)max_launches * 2) {
+        hipEvent_t e;
+        BT_HIP(hipEventCreate(&e));
+        p.pool.push_back(e);
+    }
+    p.used = 0;
+    p.recs.clear();
+    p.pending = nullptr;
+    p.on = true;
+    return BT_OK;
+}
+
+int bt_profile_stop(int *counts, double *total_ms, int n_ids) {
+    Profiler &p = g_prof;
+    p.on = false;
+    BT_REQUIRE(counts && total_ms && n_ids >= BTK_COUNT, "bt_profile_stop: need arrays of bt_profile_num_kernels() entries");
+    for (int i = 0; i < n_ids; i++) counts[i] = 0, total_ms[i] = 0.0;
+    for (const ProfRec &r : p.recs) {
+        BT_HIP(hipEventSynchronize(r.b));
+        float ms = 0.0f;
+        BT_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        counts[r.id]++;
+        total_ms[r.id] += ms;
+    }
+    p.recs.clear();
+    p.used = 0;
+    return BT_OK;
+}
+
+int bt_profile_num_kernels(void) { return BTK_COUNT; }
+
+const char *bt_profile_kernel_name(int id) { return (id >= 0 && id < BTK_COUNT) ? kKernelNames[id] : ""; }
+
+int bt_version(void) { return 1; }
+
+const char *bt_last_error(void) { return g_last_error.c_str(); }
+
+int bt_device_count(int *count) {
+    BT_REQUIRE(count, "bt_device_count: null argument");
+    BT_HIP(hipGetDeviceCount(count));
+    return BT_OK;
+}
+
+int bt_device_set(int ordinal) {
+    BT_HIP(hipSetDevice(ordinal));
+    return BT_OK;
+}
+
+int bt_device_props(int ordinal, char *name, int name_len, char *arch, int arch_len, int *wave_size, int *num_cus) {
+    hipDeviceProp_t p;
+    BT_HIP(hipGetDeviceProperties(&p, ordinal));
+    if (name && name_len > 0) {
+        strncpy(name, p.name, name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (arch && arch_len > 0) {
+        strncpy(arch, p.gcnArchName, arch_len - 1);
+        arch[arch_len - 1] = 0;
+    }
+    if (wave_size) *wave_size = p.warpSize;
+    if (num_cus) *num_cus = p.multiProcessorCount;
+    return BT_OK;
+}
+
+int bt_device_sync(void) {
+    BT_HIP(hipDeviceSynchronize());
+    return BT_OK;
+}
+
+int bt_malloc(void **ptr, size_t bytes) {
+    BT_REQUIRE(ptr, "bt_malloc: null argument");
+    *ptr = nullptr;
+    if (bytes == 0) return BT_OK;
+    BT_HIP(hipMalloc(ptr, bytes));
+    hipError_t e = hipMemset(*ptr, 0, bytes);  // Buffer::zeroed, buffer.rs:112-131
+    if (e != hipSuccess) {
+        (void)hipFree(*ptr);
+        *ptr = nullptr;
+        bt_set_error("%s: %s", hipGetErrorName(e), hipGetErrorString(e));
+        return BT_ERR_HIP;
+    }
+    return BT_OK;
+}
+
+int bt_free(void *ptr) {
+    if (!ptr) return BT_OK;
+    BT_HIP(hipFree(ptr));
+    return BT_OK;
+}
+
+int bt_host_alloc_pinned(void **ptr, size_t bytes) {
+    BT_REQUIRE(ptr, "bt_host_alloc_pinned: null argument");
+    BT_HIP(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+    return BT_OK;
+}
+
+int bt_host_free_pinned(void *ptr) {
+    if (!ptr) return BT_OK;
+    BT_HIP(hipHostFree(ptr));
+    return BT_OK;
+}
+
+int bt_stream_create(void **stream) {
+    BT_REQUIRE(stream, "bt_stream_create: null argument");
+    hipStream_t s;
+    BT_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return BT_OK;
+}
+
+int bt_stream_destroy(void *stream) {
+    if (!stream) return BT_OK;
+    BT_HIP(hipStreamDestroy(bt_stream(stream)));
+    return BT_OK;
+}
+
+int bt_stream_sync(void *stream) {
+    BT_HIP(hipStreamSynchronize(bt_stream(stream)));
+    return BT_OK;
+}
+
+int bt_memset_async(void *ptr, int byte_value, size_t bytes, void *stream) {
+    if (bytes == 0) return BT_OK;
+    BT_REQUIRE(ptr, "bt_memset_async: null pointer");
+    BT_HIP(hipMemsetAsync(ptr, byte_value, bytes, bt_stream(stream)));
+    return BT_OK;
+}
+
+int bt_memcpy_h2d_async(void *dst, const void *src_host, size_t bytes, void *stream) {
+    if (bytes == 0) return BT_OK;
+    BT_REQUIRE(dst && src_host, "bt_memcpy_h2d_async: null pointer");
+    BT_HIP(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, bt_stream(stream)));
+    return BT_OK;
+}
+
+int bt_memcpy_d2h_async(void *dst_host, const void *src, size_t bytes, void *stream) {
+    if (bytes == 0) return BT_OK;
+    BT_REQUIRE(dst_host && src, "bt_memcpy_d2h_async: null pointer");
+    BT_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, bt_stream(stream)));
+    return BT_OK;
+}
+
+int bt_memcpy_d2d_async(void *dst, const void *src, size_t bytes, void *stream) {
+    if (bytes == 0) return BT_OK;
+    BT_REQUIRE(dst && src, "bt_memcpy_d2d_async: null pointer");
+    BT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, bt_stream(stream)));
+    return BT_OK;
+}
+
+}  // extern "C"

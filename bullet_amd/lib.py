@@ -1,0 +1,254 @@
+"""ctypes binding of libbullet_amd.so (include/bullet_amd.h). Fails loudly if the library is missing."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libbullet_amd.so")
+
+ACT = {"identity": 0, "relu": 1, "crelu": 2, "screlu": 3, "sqrrelu": 4}
+INPUT = {"chess768": 0, "chess_buckets": 1, "chess_buckets_mirrored": 2, "ataxx147": 3, "ataxx98": 4}
+MAX_DENSE = 4
+ADAMW_MAX_TENSORS = 16
+
+
+class BtError(RuntimeError):
+    pass
+
+
+class FtDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in
+                ("batch", "rows", "cols", "stride", "offset", "nnz", "act", "pairwise", "n_inputs", "out_ld")]
+
+
+class DenseDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("batch", "in_", "out", "buckets", "act")]
+
+
+class AdamwTensor(C.Structure):
+    _fields_ = [("grad", C.c_void_p), ("param", C.c_void_p), ("momentum", C.c_void_p), ("velocity", C.c_void_p),
+                ("n", C.c_size_t), ("decay", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("min_weight", C.c_float), ("max_weight", C.c_float)]
+
+
+class NetDesc(C.Structure):
+    _fields_ = [
+        ("num_inputs", C.c_int), ("nnz", C.c_int), ("ft_out", C.c_int), ("ft_act", C.c_int),
+        ("pairwise", C.c_int), ("perspectives", C.c_int), ("num_buckets", C.c_int), ("n_dense", C.c_int),
+        ("dense_out", C.c_int * MAX_DENSE), ("dense_act", C.c_int * MAX_DENSE),
+        ("dense_bucketed", C.c_int * MAX_DENSE), ("use_entry_weights", C.c_int),
+    ]
+
+
+class Batch(C.Structure):
+    _fields_ = [("batch", C.c_int), ("stm", C.c_void_p), ("nstm", C.c_void_p), ("buckets", C.c_void_p),
+                ("targets", C.c_void_p), ("entry_weights", C.c_void_p)]
+
+
+class InputDesc(C.Structure):
+    _fields_ = [("kind", C.c_int), ("factorised", C.c_int), ("buckets", C.c_int * 64), ("num_buckets", C.c_int)]
+
+
+class MapOpts(C.Structure):
+    _fields_ = [("out_buckets", C.c_int), ("blend", C.c_float), ("eval_scale", C.c_float),
+                ("use_win_rate_model", C.c_int), ("wdl_output", C.c_int), ("threads", C.c_int)]
+
+
+# every symbol include/bullet_amd.h declares (tests/test_abi.py checks the .so exports them all)
+SYMBOLS = [
+    "bt_version", "bt_last_error",
+    "bt_device_count", "bt_device_set", "bt_device_props", "bt_device_sync", "bt_malloc", "bt_free",
+    "bt_host_alloc_pinned", "bt_host_free_pinned", "bt_stream_create", "bt_stream_destroy", "bt_stream_sync",
+    "bt_memset_async", "bt_memcpy_h2d_async", "bt_memcpy_d2h_async", "bt_memcpy_d2d_async",
+    "bt_profile_start", "bt_profile_stop", "bt_profile_num_kernels", "bt_profile_kernel_name",
+    "bt_ft_forward", "bt_ft_backward_workspace_bytes", "bt_ft_backward",
+    "bt_dense_forward", "bt_dense_backward_workspace_bytes", "bt_dense_backward",
+    "bt_sigmoid_mse", "bt_adamw",
+    "bt_net_param_count", "bt_net_num_tensors", "bt_net_tensor_size", "bt_net_tensor_offset", "bt_net_create",
+    "bt_net_destroy", "bt_net_params", "bt_net_grads", "bt_net_momentum", "bt_net_velocity", "bt_net_set_adamw",
+    "bt_net_forward_backward", "bt_net_optimiser_step", "bt_net_forward",
+    "bt_input_init", "bt_input_num_inputs", "bt_input_max_active", "bt_map_batch",
+]
+
+_lib = None
+
+
+def load():
+    """Load libbullet_amd.so; raises BtError (never falls back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise BtError(f"{SO_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(SO_PATH)
+    L.bt_last_error.restype = C.c_char_p
+    L.bt_profile_kernel_name.restype = C.c_char_p
+    L.bt_profile_stop.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int]
+    for f in ("bt_ft_backward_workspace_bytes", "bt_dense_backward_workspace_bytes", "bt_net_param_count",
+              "bt_net_tensor_size", "bt_net_tensor_offset"):
+        getattr(L, f).restype = C.c_size_t
+    for f in ("bt_net_params", "bt_net_grads", "bt_net_momentum", "bt_net_velocity"):
+        getattr(L, f).restype = C.c_void_p
+        getattr(L, f).argtypes = [C.c_void_p]
+    L.bt_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    L.bt_free.argtypes = [C.c_void_p]
+    L.bt_host_alloc_pinned.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    L.bt_host_free_pinned.argtypes = [C.c_void_p]
+    L.bt_stream_sync.argtypes = [C.c_void_p]
+    L.bt_memset_async.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    for f in ("bt_memcpy_h2d_async", "bt_memcpy_d2h_async", "bt_memcpy_d2d_async"):
+        getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.bt_ft_forward.argtypes = [C.c_void_p, C.POINTER(FtDesc), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
+                                C.c_void_p, C.c_void_p]
+    L.bt_ft_backward_workspace_bytes.argtypes = [C.POINTER(FtDesc)]
+    L.bt_ft_backward.argtypes = [C.c_void_p, C.POINTER(FtDesc), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.bt_dense_forward.argtypes = [C.c_void_p, C.POINTER(DenseDesc)] + [C.c_void_p] * 5
+    L.bt_dense_backward_workspace_bytes.argtypes = [C.POINTER(DenseDesc)]
+    L.bt_dense_backward.argtypes = [C.c_void_p, C.POINTER(DenseDesc)] + [C.c_void_p] * 9 + [C.c_size_t]
+    L.bt_sigmoid_mse.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+    L.bt_adamw.argtypes = [C.c_void_p, C.c_int, C.POINTER(AdamwTensor), C.c_void_p, C.c_void_p]
+    L.bt_net_param_count.argtypes = [C.POINTER(NetDesc)]
+    L.bt_net_num_tensors.argtypes = [C.POINTER(NetDesc)]
+    L.bt_net_tensor_size.argtypes = [C.POINTER(NetDesc), C.c_int]
+    L.bt_net_tensor_offset.argtypes = [C.POINTER(NetDesc), C.c_int]
+    L.bt_net_create.argtypes = [C.POINTER(NetDesc), C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.bt_net_destroy.argtypes = [C.c_void_p]
+    L.bt_net_set_adamw.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 5
+    L.bt_net_forward_backward.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.c_void_p]
+    L.bt_net_optimiser_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bt_net_forward.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]
+    L.bt_input_init.argtypes = [C.POINTER(InputDesc), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+    L.bt_input_num_inputs.argtypes = [C.POINTER(InputDesc)]
+    L.bt_input_max_active.argtypes = [C.POINTER(InputDesc)]
+    L.bt_map_batch.argtypes = [C.POINTER(InputDesc), C.POINTER(MapOpts), C.c_void_p, C.c_int] + [C.c_void_p] * 5
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise BtError(f"[{rc}] {load().bt_last_error().decode()}")
+
+
+def profile_start(max_launches=100000):
+    check(load().bt_profile_start(max_launches))
+
+
+def profile_stop():
+    """-> {kernel_name: (launches, total_ms)} for kernels that ran"""
+    L = load()
+    n = L.bt_profile_num_kernels()
+    counts, total = (C.c_int * n)(), (C.c_double * n)()
+    check(L.bt_profile_stop(counts, total, n))
+    return {L.bt_profile_kernel_name(i).decode(): (counts[i], total[i]) for i in range(n) if counts[i]}
+
+
+def make_net_desc(num_inputs, nnz, ft_out, ft_act, dense, pairwise=False, perspectives=2, num_buckets=1,
+                  use_entry_weights=False):
+    """dense: list of (out_per_bucket, act_name, bucketed)"""
+    d = NetDesc()
+    d.num_inputs, d.nnz, d.ft_out, d.ft_act = num_inputs, nnz, ft_out, ACT[ft_act]
+    d.pairwise, d.perspectives, d.num_buckets, d.n_dense = int(pairwise), perspectives, num_buckets, len(dense)
+    for k, (o, a, bk) in enumerate(dense):
+        d.dense_out[k], d.dense_act[k], d.dense_bucketed[k] = o, ACT[a], int(bk)
+    d.use_entry_weights = int(use_entry_weights)
+    return d
+
+
+def make_input_desc(kind, factorised=False, layout=None):
+    d = InputDesc()
+    lay = (C.c_int * len(layout))(*layout) if layout is not None else None
+    check(load().bt_input_init(C.byref(d), INPUT[kind], int(factorised), lay, len(layout) if layout else 0))
+    return d
+
+
+def map_batch(idesc, records, out_buckets=1, blend=0.0, eval_scale=400.0, win_rate_model=False, wdl=False,
+              threads=1, out=None):
+    """Host batch preparation through the C ABI. records: numpy uint8 [count*32]."""
+    import numpy as np
+    L = load()
+    count = records.size // 32
+    nnz = L.bt_input_max_active(C.byref(idesc))
+    if out is None:
+        out = (np.zeros((count, nnz), np.int32), np.zeros((count, nnz), np.int32), np.zeros(count, np.int32),
+               np.zeros(count * (3 if wdl else 1), np.float32), np.zeros(count, np.float32))
+    o = MapOpts(out_buckets, blend, eval_scale, int(win_rate_model), int(wdl), threads)
+    check(L.bt_map_batch(C.byref(idesc), C.byref(o), records.ctypes.data, count, *[a.ctypes.data for a in out]))
+    return out
+
+
+class Net:
+    """Thin owner of a bt_net plus torch views of its flat buffers (device memory plumbing only)."""
+
+    def __init__(self, desc, max_batch, device="cuda"):
+        import torch
+        self.L = load()
+        self.desc = desc
+        self.max_batch = max_batch
+        self.n_tensors = self.L.bt_net_num_tensors(C.byref(desc))
+        self.sizes = [self.L.bt_net_tensor_size(C.byref(desc), t) for t in range(self.n_tensors)]
+        self.offsets = [self.L.bt_net_tensor_offset(C.byref(desc), t) for t in range(self.n_tensors)]
+        self.n_flat = self.L.bt_net_param_count(C.byref(desc))
+        # flat params / grads live in torch tensors so a harness can all-reduce / copy them
+        self.params = torch.zeros(self.n_flat, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(self.n_flat, dtype=torch.float32, device=device)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=device)
+        h = C.c_void_p()
+        check(self.L.bt_net_create(C.byref(desc), max_batch, self.params.data_ptr(), self.grads.data_ptr(),
+                                   C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.bt_net_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def tensor(self, flat, t):
+        return flat[self.offsets[t]:self.offsets[t] + self.sizes[t]]
+
+    def set_params(self, arrays):
+        import torch
+        for t, a in enumerate(arrays):
+            self.tensor(self.params, t).copy_(torch.from_numpy(a).to(self.params.device))
+
+    def get_tensors(self, flat):
+        return [self.tensor(flat, t).detach().cpu().numpy().copy() for t in range(self.n_tensors)]
+
+    def state_view(self, which):
+        """momentum / velocity as numpy lists (copies)"""
+        import numpy as np
+        import torch
+        ptr = (self.L.bt_net_momentum if which == "momentum" else self.L.bt_net_velocity)(self.h)
+        host = np.zeros(self.n_flat, dtype=np.float32)
+        torch.cuda.synchronize()
+        check(self.L.bt_memcpy_d2h_async(host.ctypes.data, ptr, host.nbytes, None))
+        check(self.L.bt_device_sync())
+        return [host[o:o + s].copy() for o, s in zip(self.offsets, self.sizes)]
+
+    def make_batch(self, stm, nstm, buckets, targets, weights=None):
+        b = Batch()
+        b.batch = targets.shape[0]
+        b.stm = stm.data_ptr()
+        b.nstm = nstm.data_ptr() if nstm is not None else None
+        b.buckets = buckets.data_ptr() if buckets is not None else None
+        b.targets = targets.data_ptr()
+        b.entry_weights = weights.data_ptr() if weights is not None else None
+        b._keep = (stm, nstm, buckets, targets, weights)
+        return b
+
+    def forward_backward(self, batch, stream=None):
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        check(self.L.bt_net_forward_backward(self.h, s, C.byref(batch), self.loss.data_ptr()))
+
+    def optimiser_step(self, adj_dev, lr_dev, stream=None):
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        check(self.L.bt_net_optimiser_step(self.h, s, adj_dev.data_ptr(), lr_dev.data_ptr()))

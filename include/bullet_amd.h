@@ -1,0 +1,271 @@
+/*
+ * bullet_amd.h -- C ABI of libbullet_amd.so: an MI355X (gfx950) native backend for the
+ * training hot path of jw1912/bullet.  Plain C types only; every pointer named *_dev / w /
+ * out / grad etc. is a DEVICE pointer unless the comment says host.  All entry points return
+ * 0 on success and a non-zero code on failure; bt_last_error() then returns a thread-local
+ * "<hipErrorName>: <string>" / "Mismatched sizes!"-style message, mirroring
+ * crates/gpu/src/runtime/rocm.rs:295-311 and crates/gpu/src/function.rs:209-240.
+ *
+ * The reference's backend seam is the private trait `GpuBindings`
+ * (crates/gpu/src/runtime/bindings.rs:66-174) -- that level receives kernel *source text*, so a
+ * hand-written-kernel backend binds one level up, at `Function::execute`
+ * (crates/gpu/src/function.rs:198-280) and `OptimiserState::update`
+ * (crates/trainer/src/optimiser.rs:65-86).  Section 1 below replaces the GpuBindings memory /
+ * stream primitives, section 2 the lowered operators that Function::execute replays, section 3
+ * the whole lowered fwd+bwd+optimiser step for the value-net family of examples/ (one call per
+ * batch, what run::train's loop body does at crates/trainer/src/run.rs:185-221), section 4 the
+ * host batch preparation (crates/bullet_lib/src/value.rs:55-118).
+ *
+ * Citations are file:line relative to the reference checkout (jw1912/bullet @ 2026-06-30).
+ */
+#ifndef BULLET_AMD_H
+#define BULLET_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BT_OK 0
+#define BT_ERR_INVALID 1   /* shape / argument check failed ("Mismatched sizes!") */
+#define BT_ERR_HIP 2       /* a HIP runtime call failed                            */
+#define BT_ERR_STATE 3     /* object used in the wrong state                       */
+#define BT_ERR_IO 4        /* host file I/O                                        */
+
+/* Fused activation ids (DiffableFromOutput family, crates/compiler/src/tensor/operation/autograd/dfo.rs:47-103) */
+enum {
+    BT_ACT_IDENTITY = 0,
+    BT_ACT_RELU = 1,
+    BT_ACT_CRELU = 2,
+    BT_ACT_SCRELU = 3,
+    BT_ACT_SQRRELU = 4,
+};
+
+int bt_version(void);
+/* Thread-local message of the last failing call on this thread; "" if none. */
+const char *bt_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * 1. Runtime primitives  (replaces GpuBindings, bindings.rs:76-125; ROCm impl rocm.rs:66-171)
+ * ------------------------------------------------------------------------------------------ */
+
+/* device_get / context_set, bindings.rs:78-86 (every reference wrapper call does hipSetDevice first,
+ * crates/gpu/src/runtime.rs:84-86). */
+int bt_device_count(int *count);
+int bt_device_set(int ordinal);
+/* device_props, bindings.rs:80: name + gcnArchName + wavefront size */
+int bt_device_props(int ordinal, char *name, int name_len, char *arch, int arch_len, int *wave_size, int *num_cus);
+/* context_sync, bindings.rs:88 */
+int bt_device_sync(void);
+/* context_malloc + context_memset(0) = Buffer::zeroed, bindings.rs:90-94, crates/gpu/src/buffer.rs:112-131 */
+int bt_malloc(void **ptr, size_t bytes);
+int bt_free(void *ptr);
+/* pinned host staging (the reference uploads from pageable Vecs, run/dataloader.rs:72-116) */
+int bt_host_alloc_pinned(void **ptr, size_t bytes);
+int bt_host_free_pinned(void *ptr);
+/* stream_create/destroy/sync, bindings.rs:100-104. A stream is a hipStream_t passed as void*;
+ * NULL means the default stream, and any hipStream_t created elsewhere (e.g. by PyTorch) is accepted. */
+int bt_stream_create(void **stream);
+int bt_stream_destroy(void *stream);
+int bt_stream_sync(void *stream);
+/* stream_memset / stream_memcpy_h2d / stream_memcpy_d2h, bindings.rs:110-125 */
+int bt_memset_async(void *ptr, int byte_value, size_t bytes, void *stream);
+int bt_memcpy_h2d_async(void *dst, const void *src_host, size_t bytes, void *stream);
+int bt_memcpy_d2h_async(void *dst_host, const void *src, size_t bytes, void *stream);
+int bt_memcpy_d2d_async(void *dst, const void *src, size_t bytes, void *stream);
+
+/* Per-kernel timing with HIP events recorded on the stream each kernel is launched on (the reference
+ * only has wall-clock pos/sec, crates/trainer/src/run/logger.rs:38-77). bt_profile_start arms the
+ * calling thread's profiler for up to max_launches kernel launches; bt_profile_stop waits for the
+ * events and fills counts[id] / total_ms[id] for id < bt_profile_num_kernels(). */
+int bt_profile_start(int max_launches);
+int bt_profile_stop(int *counts, double *total_ms, int n_ids);
+int bt_profile_num_kernels(void);
+const char *bt_profile_kernel_name(int id);
+
+/* ------------------------------------------------------------------------------------------
+ * 2. Operators  (what Function::execute replays, function.rs:198-280; kernel inventory SURVEY 2.1)
+ * ------------------------------------------------------------------------------------------ */
+
+/* Sparse feature transformer = SparseMatmul (+ bias broadcast + activation [+ pairwise product]),
+ * crates/compiler/src/tensor/operation/linear/sparse.rs:7-15,86-119 with the device stop rule of
+ * crates/gpu/src/pointwise/write.rs:229-233 (stop at the first index < 0 or >= cols), fused with
+ * Affine::forward's bias add (crates/compiler/src/model/builder.rs:145-147) and the activation
+ * peepholes (foldrules.rs:173-231).  Several sparse inputs ("perspectives", stm/nstm) may share
+ * one weight matrix, as l0.forward(stm) / l0.forward(ntm) do in every example; their outputs are
+ * written side by side (the `concat` of model/operations/index.rs:74-81 is never materialised). */
+typedef struct {
+    int batch;    /* B                                                             */
+    int rows;     /* output rows of the op (H)                                     */
+    int cols;     /* F: number of features; valid indices are 0 <= j < cols        */
+    int stride;   /* column stride of W in floats (>= offset + rows)               */
+    int offset;   /* row offset inside each column                                 */
+    int nnz;      /* N: index slots per position                                   */
+    int act;      /* BT_ACT_*                                                      */
+    int pairwise; /* 1: out[r] = act(x[r]) * act(x[r + rows/2]), r < rows/2 (builder.rs:390-393) */
+    int n_inputs; /* 1 or 2 sparse inputs sharing W                                */
+    int out_ld;   /* floats per position in `out`; input k occupies columns [k*out_w, (k+1)*out_w),
+                     out_w = pairwise ? rows/2 : rows                              */
+} bt_ft_desc;
+
+/* w: F32[stride*cols] column-major (docs/4-saved-networks.md:21-29); bias: F32[rows] or NULL;
+ * idx[k]: I32[batch*nnz]; out: F32[batch*out_ld];
+ * saved: pairwise only, F32[n_inputs*batch*rows] receiving act(x) before the product (needed by
+ * the backward); NULL otherwise (the backward differentiates from `out`). */
+int bt_ft_forward(void *stream, const bt_ft_desc *desc, const float *w, const float *bias,
+                  const int32_t *const *idx, float *out, float *saved);
+
+/* Scratch size for bt_ft_backward (index lists, partial sums). */
+size_t bt_ft_backward_workspace_bytes(const bt_ft_desc *desc);
+
+/* SparseMatmulBwdMulti (sparse.rs:198-271; merge rule rewriterules.rs:267-301) fused with the
+ * activation derivative from the output (dfo.rs:30-40) and the bias-gradient batch sum
+ * (linear/reduce.rs:96-120).  Replaces the float-atomic SpMMT template (write.rs:294-307): each
+ * dw element is a sorted-by-feature segmented sum in a fixed order, bit-reproducible run to run.
+ * grad_out: F32[batch*out_ld] gradient w.r.t. `out`; out/saved as produced by bt_ft_forward.
+ * dw: F32[stride*cols], fully overwritten (no pre-zeroing needed); dbias: F32[rows] or NULL. */
+int bt_ft_backward(void *stream, const bt_ft_desc *desc, const int32_t *const *idx, const float *grad_out,
+                   const float *out, const float *saved, float *dw, float *dbias, void *workspace,
+                   size_t workspace_bytes);
+
+/* Dense affine layer with optional output-bucket select and activation:
+ * Matmul (linear/matmul.rs:62-93, lowered model/operations/linear.rs:128-149, device
+ * function.rs:256-274 -> hipblasSgemm) + bias broadcast + Select (index/select.rs:12-26) + activation.
+ * w: F32[(out*buckets) x in] column-major; bias F32[out*buckets]; x: F32[batch*in];
+ * bucket: I32[batch] (ignored when buckets == 1); y: F32[batch*out] (activated). */
+typedef struct {
+    int batch;
+    int in;      /* input width                     */
+    int out;     /* outputs per bucket              */
+    int buckets; /* 1 = no select                   */
+    int act;     /* BT_ACT_* applied after select   */
+} bt_dense_desc;
+
+int bt_dense_forward(void *stream, const bt_dense_desc *desc, const float *w, const float *bias, const float *x,
+                     const int32_t *bucket, float *y);
+size_t bt_dense_backward_workspace_bytes(const bt_dense_desc *desc);
+/* Matmul::backward (matmul.rs:99-126) + SelectPad (select.rs:93-110) + bias batch-sum + activation
+ * derivative from output. grad_y: F32[batch*out] w.r.t. the activated y. Writes dw (full, rows of
+ * unselected buckets get exact zeros), dbias, and grad_x F32[batch*in] (may be NULL). */
+int bt_dense_backward(void *stream, const bt_dense_desc *desc, const float *w, const float *x,
+                      const int32_t *bucket, const float *y, const float *grad_y, float *dw, float *dbias,
+                      float *grad_x, void *workspace, size_t workspace_bytes);
+
+/* sigmoid + squared error (+ entry weight) + batch sum and its gradient in one pass:
+ * model/operations/pointwise.rs:141-165, model/builder.rs:351-354, value/builder.rs:137-142,
+ * derivative rules binary.rs:101-123 and dfo.rs:105-119.
+ * y: F32[batch] raw net output; loss_sum: F32[1] (overwritten, un-normalised: run.rs:221 divides by B);
+ * grad_y: F32[batch] d(loss_sum)/dy; entry_weights may be NULL. */
+int bt_sigmoid_mse(void *stream, int batch, const float *y, const float *targets, const float *entry_weights,
+                   float *loss_sum, float *grad_y);
+
+/* AdamW, crates/trainer/src/optimiser/adam.rs:29-62,98-235; one launch for all weight tensors
+ * (the reference launches once per tensor, optimiser.rs:175-187). adj_dev / lr_dev are 1-element
+ * device buffers exactly as in run.rs:130-133. */
+typedef struct {
+    const float *grad;
+    float *param, *momentum, *velocity;
+    size_t n;
+    float decay, beta1, beta2, min_weight, max_weight; /* AdamWParams, adam.rs:20-33 */
+} bt_adamw_tensor;
+#define BT_ADAMW_MAX_TENSORS 16
+int bt_adamw(void *stream, int n_tensors, const bt_adamw_tensor *tensors /* host */, const float *adj_dev,
+             const float *lr_dev);
+
+/* ------------------------------------------------------------------------------------------
+ * 3. The lowered training step for the ValueTrainerBuilder net family
+ *    (crates/bullet_lib/src/value/builder.rs:118-181; step = run.rs:185-221)
+ * ------------------------------------------------------------------------------------------ */
+#define BT_MAX_DENSE 4
+typedef struct {
+    int num_inputs;   /* F */
+    int nnz;          /* N */
+    int ft_out;       /* H */
+    int ft_act;       /* BT_ACT_* */
+    int pairwise;     /* examples/progression/4_multi_layer.rs:79-81 */
+    int perspectives; /* 1 = single_perspective, 2 = dual_perspective (value/builder.rs:217-245) */
+    int num_buckets;  /* OutputBuckets::BUCKETS (game/outputs.rs:3-7); 1 = none */
+    int n_dense;
+    int dense_out[BT_MAX_DENSE];
+    int dense_act[BT_MAX_DENSE];
+    int dense_bucketed[BT_MAX_DENSE];
+    int use_entry_weights;
+} bt_net_desc;
+
+typedef struct bt_net bt_net; /* opaque: weights, AdamW state, gradients, activations, scratch */
+
+/* Allocates every device buffer for `max_batch` positions on the current device.
+ * ext_params / ext_grads: optional caller-owned flat device buffers of bt_net_param_count()
+ * floats (so a harness can all-reduce the flat gradient); NULL -> library-owned. */
+size_t bt_net_param_count(const bt_net_desc *desc);
+int bt_net_num_tensors(const bt_net_desc *desc);
+size_t bt_net_tensor_size(const bt_net_desc *desc, int tensor);
+/* offset (in floats) of a tensor inside the flat buffers; tensors are padded to 4 floats */
+size_t bt_net_tensor_offset(const bt_net_desc *desc, int tensor);
+int bt_net_create(const bt_net_desc *desc, int max_batch, float *ext_params, float *ext_grads, bt_net **net);
+int bt_net_destroy(bt_net *net);
+/* flat views (tensor order l0w,l0b,l1w,l1b,...: creation order, weights.rs:57) */
+float *bt_net_params(bt_net *net);
+float *bt_net_grads(bt_net *net);
+float *bt_net_momentum(bt_net *net);
+float *bt_net_velocity(bt_net *net);
+/* per-tensor AdamW overrides = Optimiser::set_params_for_weight, optimiser.rs:204-206 */
+int bt_net_set_adamw(bt_net *net, int tensor, float decay, float beta1, float beta2, float min_w, float max_w);
+
+/* Device batch tensors, layouts of crates/bullet_lib/src/value.rs:70-75. nstm may be NULL for
+ * single-perspective nets, buckets NULL when num_buckets == 1, entry_weights NULL when unused. */
+typedef struct {
+    int batch;
+    const int32_t *stm, *nstm, *buckets;
+    const float *targets, *entry_weights;
+} bt_batch;
+
+/* fwd + bwd: fills the flat gradient (unscaled batch sums, run.rs:130) and loss_sum_dev[0]. */
+int bt_net_forward_backward(bt_net *net, void *stream, const bt_batch *batch, float *loss_sum_dev);
+/* AdamW on every tensor with g = adj * grad (adj = 1/global_batch), adam.rs:121-131 */
+int bt_net_optimiser_step(bt_net *net, void *stream, const float *adj_dev, const float *lr_dev);
+/* forward only (ModelEvaluator, crates/trainer/src/model/evaluator.rs:50-81): raw outputs F32[batch] */
+int bt_net_forward(bt_net *net, void *stream, const bt_batch *batch, float *out_dev, float *loss_sum_dev);
+
+/* ------------------------------------------------------------------------------------------
+ * 4. Host batch preparation (crates/bullet_lib/src/value.rs:55-118, game/inputs/, game/outputs.rs)
+ * ------------------------------------------------------------------------------------------ */
+enum {
+    BT_INPUT_CHESS768 = 0,
+    BT_INPUT_CHESS_BUCKETS = 1,
+    BT_INPUT_CHESS_BUCKETS_MIRRORED = 2,
+    BT_INPUT_ATAXX147 = 3,
+    BT_INPUT_ATAXX98 = 4,
+};
+typedef struct {
+    int kind;        /* BT_INPUT_* */
+    int factorised;  /* game/inputs/factorised.rs (Chess768 factoriser) */
+    int buckets[64]; /* expanded king-bucket table (chess_buckets.rs:11-15,56-67) */
+    int num_buckets;
+} bt_input_desc;
+
+int bt_input_init(bt_input_desc *d, int kind, int factorised, const int *layout, int layout_len);
+int bt_input_num_inputs(const bt_input_desc *d);
+int bt_input_max_active(const bt_input_desc *d);
+
+typedef struct {
+    int out_buckets;        /* MaterialCount<N>; <=1 -> bucket 0 */
+    float blend;            /* WDL lambda for this step (WdlScheduler::blend) */
+    float eval_scale;       /* TrainingSchedule::eval_scale */
+    int use_win_rate_model; /* value.rs:104-108 */
+    int wdl_output;         /* value.rs:96-101: 3-way one-hot target */
+    int threads;            /* ModelInputsMapper::map fan-out, model/inputs.rs:86-109 */
+} bt_map_opts;
+
+/* records: host, count*32 bytes of ChessBoard / AtaxxBoard. Outputs are HOST buffers (pinned
+ * recommended): stm,nstm I32[count*nnz]; buckets I32[count]; targets F32[count or 3*count];
+ * weights F32[count]. Slots after the -1 terminator are left untouched (value.rs:86-89). */
+int bt_map_batch(const bt_input_desc *d, const bt_map_opts *o, const void *records, int count, int32_t *stm,
+                 int32_t *nstm, int32_t *buckets, float *targets, float *weights);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,177 @@
+"""-m gpu: the whole lowered training step (bt_net_*) against the CPU oracle and against the
+reference's own e2e anchors (examples/tests/test1.rs:54, test3.rs:45 on examples/tests/batch.bf)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+import oracle_binding as ob  # noqa: E402
+from bullet_amd import lib  # noqa: E402
+import gpu_util as gu  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "batch.bf")
+MIRROR_LAYOUT = [0, 1, 2, 3, 4, 4, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8, 8, 8, 9, 9, 9, 9, 9, 9, 9, 9]
+
+
+def run_steps(cfg, batches, steps, lr=0.001, ft_eff=0, seed=198273612, clip=None):
+    """Runs `steps` optimiser steps on both the device net and the oracle from identical weights.
+    batches: list of (stm, ntm, buckets, targets, weights). Returns per-step losses and final tensors."""
+    dn, do = lib.make_net_desc(**cfg), ob.make_net(**cfg)
+    params = ob.net_init(do, seed, ft_eff)
+    B = batches[0][3].shape[0]
+    net = lib.Net(dn, B)
+    net.set_params(params)
+    if clip:
+        for t in clip:
+            lib.check(net.L.bt_net_set_adamw(net.h, t, 0.01, 0.9, 0.999, -0.99, 0.99))
+    m = [np.zeros_like(p) for p in params]
+    v = [np.zeros_like(p) for p in params]
+    adj, lrd = torch.tensor([1.0 / B], device="cuda"), torch.tensor([lr], device="cuda")
+    dl, ol, first_grads = [], [], None
+    for s in range(steps):
+        stm, ntm, bk, tg, w = batches[s % len(batches)]
+        tb = net.make_batch(gu.dev(stm), gu.dev(ntm), gu.dev(bk), gu.dev(tg), gu.dev(w))
+        net.forward_backward(tb)
+        torch.cuda.synchronize()
+        dl.append(net.loss.item() / B)
+        loss, grads, _ = ob.net_fwd_bwd(do, params, stm, ntm, bk, tg, w)
+        ol.append(loss / B)
+        if s == 0:
+            first_grads = (net.get_tensors(net.grads), grads)
+        net.optimiser_step(adj, lrd)
+        for t, (p_, m_, v_, g_) in enumerate(zip(params, m, v, grads)):
+            if clip and t in clip:
+                ob.adamw(p_, m_, v_, g_, 1.0 / B, lr, wmin=-0.99, wmax=0.99)
+            else:
+                ob.adamw(p_, m_, v_, g_, 1.0 / B, lr)
+    torch.cuda.synchronize()
+    out = dict(dev_loss=dl, orc_loss=ol, dev_params=net.get_tensors(net.params), orc_params=params,
+               first_grads=first_grads, dev_m=net.state_view("momentum"), orc_m=m)
+    net.close()
+    return out
+
+
+def fixture_batches(kind, layout, fact, n_out_buckets, blend, nbatches, batch=16384):
+    rec = np.fromfile(GOLDEN, dtype=np.uint8).reshape(-1, 32)
+    n = rec.shape[0]
+    idesc = lib.make_input_desc(kind, fact, layout)
+    out, pos = [], 0
+    for _ in range(nbatches):
+        sel = np.arange(pos, pos + batch) % n
+        pos += batch
+        out.append(lib.map_batch(idesc, rec[sel].reshape(-1).copy(), out_buckets=n_out_buckets, blend=blend,
+                                 threads=4))
+    return out
+
+
+@pytest.mark.parametrize("hidden,expected", [(32, "0.056420"), (128, "0.044886")])
+def test_reference_e2e_losses_on_device(hidden, expected):
+    """examples/tests/test1.rs / test3.rs: 10 steps, batch 16384, lr 1e-3, wdl 0.2 -> printed loss."""
+    cfg = dict(num_inputs=768, nnz=32, ft_out=hidden, ft_act="screlu", dense=[(1, "identity", False)])
+    r = run_steps(cfg, fixture_batches("chess768", None, False, 1, 0.2, 10), 10)
+    assert "%.6f" % r["dev_loss"][-1] == expected
+    # loss and every weight after N = 10 steps within 1e-4 relative of the oracle
+    for a, b in zip(r["dev_loss"], r["orc_loss"]):
+        assert abs(a - b) <= 1e-4 * abs(b)
+    for t, (a, b) in enumerate(zip(r["dev_params"], r["orc_params"])):
+        gu.assert_close(a, b, rtol=1e-4, atol=1e-5, what=f"tensor {t} after 10 steps")
+
+
+NETS = {
+    # BASELINE.json configs at reduced batch (full-batch runs are in bench.py / test above)
+    "cfg1_simple": (dict(num_inputs=768, nnz=32, ft_out=128, ft_act="screlu", dense=[(1, "identity", False)]),
+                    ("chess768", None, False), 1, 0),
+    "cfg2_buckets": (dict(num_inputs=768, nnz=32, ft_out=1024, ft_act="screlu", num_buckets=8,
+                          dense=[(1, "identity", True)]), ("chess768", None, False), 8, 0),
+    "cfg3_multilayer": (dict(num_inputs=768 * 10, nnz=32, ft_out=256, ft_act="crelu", pairwise=True, num_buckets=8,
+                             dense=[(16, "screlu", True), (32, "screlu", True), (1, "identity", True)]),
+                        ("chess_buckets_mirrored", MIRROR_LAYOUT, False), 8, 32),
+    "single_perspective": (dict(num_inputs=768, nnz=32, ft_out=64, ft_act="crelu", perspectives=1,
+                                dense=[(8, "relu", False), (1, "identity", False)], use_entry_weights=True),
+                           ("chess768", None, False), 1, 0),
+}
+
+
+@pytest.mark.parametrize("name", list(NETS))
+def test_net_step_vs_oracle(name):
+    cfg, (kind, layout, fact), nb, ft_eff = NETS[name]
+    batches = fixture_batches(kind, layout, fact, nb, 0.75, 2, batch=1500)
+    if cfg.get("use_entry_weights"):
+        rng = np.random.default_rng(1)
+        batches = [(s, n, b, t, (rng.random(t.shape[0]) + 0.5).astype(np.float32)) for s, n, b, t, _ in batches]
+    r = run_steps(cfg, batches, 4, ft_eff=ft_eff, clip=[0] if name == "cfg3_multilayer" else None)
+    dg, og = r["first_grads"]
+    for t, (a, b) in enumerate(zip(dg, og)):
+        scale = max(float(np.abs(b).max()), 1e-6)
+        gu.assert_close(a, b, rtol=2e-4, atol=2e-5 * scale, what=f"{name}: grad tensor {t}")
+    for a, b in zip(r["dev_loss"], r["orc_loss"]):
+        assert abs(a - b) <= 1e-5 * abs(b) + 1e-7, (r["dev_loss"], r["orc_loss"])
+    for t, (a, b) in enumerate(zip(r["dev_params"], r["orc_params"])):
+        gu.assert_close(a, b, rtol=1e-4, atol=2e-5, what=f"{name}: tensor {t} after 4 steps")
+
+
+def test_ataxx_net_vs_oracle():
+    """examples/ataxx.rs shape (F=147, N=49, H=256) on synthetic AtaxxBoard records."""
+    rng = np.random.default_rng(11)
+    n = 700
+    rec = np.zeros((n, 32), dtype=np.uint8)
+    for i in range(n):
+        sq = rng.permutation(49)
+        a, b, c = rng.integers(1, 22), rng.integers(1, 22), rng.integers(0, 5)
+        bbs = [sum(1 << int(s) for s in sq[:a]), sum(1 << int(s) for s in sq[a:a + b]),
+               sum(1 << int(s) for s in sq[a + b:a + b + c])]
+        rec[i, :24] = np.array(bbs, dtype=np.uint64).view(np.uint8)
+        rec[i, 24:26] = np.array([rng.integers(-1500, 1500)], dtype=np.int16).view(np.uint8)
+        rec[i, 26] = rng.integers(0, 3)
+    batch = lib.map_batch(lib.make_input_desc("ataxx147"), rec.reshape(-1), blend=0.5)
+    cfg = dict(num_inputs=147, nnz=49, ft_out=256, ft_act="screlu", dense=[(1, "identity", False)])
+    r = run_steps(cfg, [batch], 3)
+    for a, b in zip(r["dev_loss"], r["orc_loss"]):
+        assert abs(a - b) <= 1e-5 * abs(b)
+    for t, (a, b) in enumerate(zip(r["dev_params"], r["orc_params"])):
+        gu.assert_close(a, b, rtol=1e-4, atol=2e-5, what=f"ataxx tensor {t}")
+
+
+def test_full_size_config2_properties():
+    """BASELINE config 2 at its full size (B = 16384, H = 1024, 8 buckets): size-independent checks.
+    (a) bit-identical gradients run to run; (b) the bias gradient equals the column sum implied by the
+    weight gradient of an always-on feature; (c) loss matches the oracle's."""
+    cfg = dict(num_inputs=768, nnz=32, ft_out=1024, ft_act="screlu", num_buckets=8, dense=[(1, "identity", True)])
+    (stm, ntm, bk, tg, w), = fixture_batches("chess768", None, False, 8, 0.75, 1)
+    dn, do = lib.make_net_desc(**cfg), ob.make_net(**cfg)
+    params = ob.net_init(do)
+    params[1][:] = 0.05  # non-zero bias so SCReLU is active on a good share of rows
+    net = lib.Net(dn, 16384)
+    net.set_params(params)
+    tb = net.make_batch(gu.dev(stm), gu.dev(ntm), gu.dev(bk), gu.dev(tg), gu.dev(w))
+    net.forward_backward(tb)
+    torch.cuda.synchronize()
+    g1, l1 = net.grads.clone(), net.loss.item()
+    net.forward_backward(tb)
+    torch.cuda.synchronize()
+    assert torch.equal(g1, net.grads) and l1 == net.loss.item()
+    loss_ref = ob.lib().orc_net_forward(C.byref(do), 16384, ob.ptr_array(params), ob.ip(stm), ob.ip(ntm), ob.ip(bk),
+                                        ob.fp(tg), ob.fp(w), None)
+    assert abs(l1 - loss_ref) <= 1e-5 * abs(loss_ref)
+    # every position has exactly one own king (types 5 => features 320..383 stm) per perspective, so
+    # sum over king features of dW0 columns == bias gradient contribution of that perspective; both
+    # perspectives: sum_f in kings(stm)+kings(ntm as seen) ... checked through total mass instead:
+    gw = net.tensor(net.grads, 0).view(768, 1024).double()
+    gb = net.tensor(net.grads, 1).double()
+    # each (position, perspective) adds its g row to exactly popcount features and once to the bias:
+    # so sum_f dW0[f] == sum over entries of cnt_e * g_e; with cnt available from the indices:
+    cnt = np.where((stm < 0).any(1), (stm < 0).argmax(1), 32)
+    assert cnt.min() >= 3
+    # own-king feature (type 5, colour 0 -> 320..383) occurs exactly once per stm list; opponent king
+    # (colour 1 -> 384+320..) exactly once: their column sums therefore equal the bias gradient.
+    own = gw[320:384].sum(0) + gw[384 + 320:384 + 384].sum(0)
+    # ntm lists contain the same two kings with colours swapped -> already included above (shared W)
+    torch.testing.assert_close(own, 2 * gb, rtol=2e-4, atol=1e-4 * float(gb.abs().max()))
+    net.close()
