@@ -16,11 +16,19 @@
 // sorted by feature (stable, so ascending entry order inside a feature) plus per-feature offsets.
 // Every dW element is then summed chunk by chunk, entry by entry, in that fixed order: the result is
 // bit-identical run to run (the reference's atomicAdd order is arbitrary).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
 
 constexpr int FT_CHUNK = 256;  // positions per index chunk (local ids fit u16)
+
+// tests: BT_FT_FORCE_GENERIC=1 runs the any-shape kernels on every shape
+bool force_generic() {
+    const char *e = getenv("BT_FT_FORCE_GENERIC");
+    return e && e[0] == '1';
+}
 
 struct float4_t {
     float x, y, z, w;
@@ -313,7 +321,269 @@ __global__ void colsum_final(const float *__restrict__ partial, int nblk, int C,
     out[c] = s;
 }
 
+
+// ================================================================== LDS-resident fast paths
+// When (cols+1) * 32 rows * 4 B fits in LDS (Chess768: 96 KiB, Ataxx: 18 KiB) each workgroup owns a
+// 32-row tile of the table for its whole life:
+//   forward : the W tile is loaded once, then every (position, feature) gather is a 128-B LDS read
+//             (ds_read_b64 x 16 lanes) instead of an L2 read -- ~8x the gather bandwidth of the L2 path;
+//   backward: the dW tile is accumulated in LDS; per chunk of 256 positions the activated gradient tile is
+//             staged once (one HBM read of grad_out/out per step) and every feature's sorted entry list
+//             is summed from LDS in a fixed order.
+// Row tile of a pairwise op = 16 rows of the first half + the matching 16 rows of the second half.
+constexpr int LDS_RT = 32;
+constexpr int LDS_THREADS = 1024;
+
+template <int N>
+__device__ __forceinline__ int row_share(int v) {  // broadcast lane N of each 16-lane row (DPP, no LDS traffic)
+    return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xF, 0xF, false);
+}
+
+__device__ __forceinline__ int tile_row(bool pair, int rt, int half_rows, int local4) {
+    // local4: float offset (multiple of 2 or 4) inside the 32-float tile -> global row
+    if (!pair) return rt * LDS_RT + local4;
+    return (local4 < 16) ? rt * 16 + local4 : half_rows + rt * 16 + (local4 - 16);
+}
+
+template <int N>
+__device__ __forceinline__ void fwd_step(const float *wl, int reg, int base, int maxcnt, int sub, float2 &acc) {
+    if (base + N < maxcnt) {  // wave-uniform
+        const int f = row_share<N>(reg);
+        const float2 v = *reinterpret_cast<const float2 *>(wl + f * LDS_RT + sub * 2);
+        acc.x += v.x;
+        acc.y += v.y;
+    }
+}
+
+template <bool PAIR, int NREG>
+__global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restrict__ w, const float *__restrict__ bias,
+                                                          const int32_t *__restrict__ idx0,
+                                                          const int32_t *__restrict__ idx1, float *__restrict__ out,
+                                                          float *__restrict__ saved, bt_ft_desc d, int ntiles,
+                                                          int entries_per_wg) {
+    extern __shared__ float wl[];  // [(cols + 1)][32]; row `cols` is all zero (target of masked slots)
+    const int rt = blockIdx.x % ntiles, grp = blockIdx.x / ntiles;
+    const int half_rows = d.rows / 2;
+    for (int q = threadIdx.x; q < d.cols * 8; q += LDS_THREADS) {
+        const int f = q >> 3, s8 = q & 7;
+        const float4 v = *reinterpret_cast<const float4 *>(w + (size_t)f * d.stride + d.offset +
+                                                            tile_row(PAIR, rt, half_rows, s8 * 4));
+        *reinterpret_cast<float4 *>(wl + f * LDS_RT + s8 * 4) = v;
+    }
+    if (threadIdx.x < LDS_RT) wl[d.cols * LDS_RT + threadIdx.x] = 0.0f;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & 15, eslot = lane >> 4;
+    const int row = tile_row(PAIR, rt, half_rows, sub * 2);
+    float2 bv = make_float2(0.0f, 0.0f);
+    if (bias) bv = *reinterpret_cast<const float2 *>(bias + row);
+    const long long E = (long long)d.n_inputs * d.batch;
+    const long long e_begin = (long long)grp * entries_per_wg;
+    const long long e_end = min(E, e_begin + entries_per_wg);
+    const int out_w = PAIR ? half_rows : d.rows;
+
+    for (long long eb = e_begin + wave * 4; eb < e_end; eb += (LDS_THREADS / 64) * 4) {
+        const long long e = eb + eslot;
+        const bool live = e < e_end;
+        const int k = live ? (int)(e / d.batch) : 0;
+        const int b = live ? (int)(e % d.batch) : 0;
+        const int32_t *ip = (k == 0 ? idx0 : idx1) + (size_t)b * d.nnz;
+        int reg[NREG];
+        int nvalid = d.nnz;
+#pragma unroll
+        for (int q = NREG - 1; q >= 0; q--) {
+            const int p = q * 16 + sub;
+            int j = -1;
+            if (live && p < d.nnz) j = ip[p];
+            reg[q] = j;
+            const bool inval = (p >= d.nnz) || j < 0 || j >= d.cols;
+            const unsigned m = (unsigned)((__ballot(inval) >> (eslot * 16)) & 0xFFFFull);
+            if (m) nvalid = q * 16 + __ffs((int)m) - 1;  // descending q: the smallest position wins
+        }
+        if (!live) nvalid = 0;
+#pragma unroll
+        for (int q = 0; q < NREG; q++)
+            if (q * 16 + sub >= nvalid) reg[q] = d.cols;  // stop rule (write.rs:231): masked slots read the zero row
+        const int maxcnt = max(max(__builtin_amdgcn_readlane(nvalid, 0), __builtin_amdgcn_readlane(nvalid, 16)),
+                               max(__builtin_amdgcn_readlane(nvalid, 32), __builtin_amdgcn_readlane(nvalid, 48)));
+        float2 acc = make_float2(0.0f, 0.0f);
+#pragma unroll
+        for (int q = 0; q < NREG; q++) {
+            const int base = q * 16;
+            fwd_step<0>(wl, reg[q], base, maxcnt, sub, acc);
+            fwd_step<1>(wl, reg[q], base, maxcnt, sub, acc);
+            fwd_step<2>(wl, reg[q], base, maxcnt, sub, acc);
+            fwd_step<3>(wl, reg[q], base, maxcnt, sub, acc);
+            fwd_step<4>(wl, reg[q], base, maxcnt, sub, acc);
+            fwd_step<5>(wl, reg[q], base, maxcnt, sub, acc);
+            fwd_step<6>(wl, reg[q], base, maxcnt, sub, acc);
+            fwd_step<7>(wl, reg[q], base, maxcnt, sub, acc);
+            fwd_step<8>(wl, reg[q], base, maxcnt, sub, acc);
+            fwd_step<9>(wl, reg[q], base, maxcnt, sub, acc);
+            fwd_step<10>(wl, reg[q], base, maxcnt, sub, acc);
+            fwd_step<11>(wl, reg[q], base, maxcnt, sub, acc);
+            fwd_step<12>(wl, reg[q], base, maxcnt, sub, acc);
+            fwd_step<13>(wl, reg[q], base, maxcnt, sub, acc);
+            fwd_step<14>(wl, reg[q], base, maxcnt, sub, acc);
+            fwd_step<15>(wl, reg[q], base, maxcnt, sub, acc);
+        }
+        float2 c = make_float2(bt_act_fwd(d.act, acc.x + bv.x), bt_act_fwd(d.act, acc.y + bv.y));
+        if constexpr (PAIR) {
+            // lanes sub and sub^8 hold the two factors of the same output column
+            const float ox = __shfl_xor(c.x, 8, 16), oy = __shfl_xor(c.y, 8, 16);
+            if (live) {
+                *reinterpret_cast<float2 *>(saved + (size_t)e * d.rows + row) = c;
+                if (sub < 8)
+                    *reinterpret_cast<float2 *>(out + (size_t)b * d.out_ld + (size_t)k * out_w + rt * 16 + sub * 2) =
+                        make_float2(c.x * ox, c.y * oy);
+            }
+        } else {
+            if (live) *reinterpret_cast<float2 *>(out + (size_t)b * d.out_ld + (size_t)k * out_w + row) = c;
+        }
+    }
+}
+
+// backward: workgroup (row tile rt, chunk group cg) -> partial_w[cg][cols][stride], partial_b[cg][rows]
+template <bool PAIR>
+__global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restrict__ grad_out,
+                                                          const float *__restrict__ out,
+                                                          const float *__restrict__ saved,
+                                                          const uint16_t *__restrict__ sorted,
+                                                          const uint32_t *__restrict__ offs,
+                                                          float *__restrict__ partial_w,
+                                                          float *__restrict__ partial_b, bt_ft_desc d, int ntiles,
+                                                          int chunks_per_input, int chunks_per_wg) {
+    extern __shared__ float lds_f[];
+    float *acc = lds_f;                                   // [cols][32]
+    float *gt = acc + (size_t)d.cols * LDS_RT;            // [FT_CHUNK][32]
+    uint32_t *offl = reinterpret_cast<uint32_t *>(gt + FT_CHUNK * LDS_RT);  // [cols + 1]
+    uint16_t *srt = reinterpret_cast<uint16_t *>(offl + ((d.cols + 1 + 1) & ~1));  // [FT_CHUNK * nnz]
+    const int rt = blockIdx.x % ntiles, cg = blockIdx.x / ntiles;
+    const int half_rows = d.rows / 2;
+    const int nchunks = d.n_inputs * chunks_per_input;
+    const int out_w = PAIR ? half_rows : d.rows;
+
+    for (int q = threadIdx.x; q < d.cols * LDS_RT; q += LDS_THREADS) acc[q] = 0.0f;
+
+    const int s8 = threadIdx.x & 7, el0 = threadIdx.x >> 3;  // staging role: 128 entries x 8 float4 per pass
+    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;  // reduce role: 64 groups of 16 lanes (float2)
+    float4 bsum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int c_lo = cg * chunks_per_wg, c_hi = min(nchunks, c_lo + chunks_per_wg);
+    for (int c = c_lo; c < c_hi; c++) {
+        const int k = c / chunks_per_input, cb = c % chunks_per_input;
+        const int b0 = cb * FT_CHUNK;
+        const int n_e = min(FT_CHUNK, d.batch - b0);
+        __syncthreads();  // previous chunk's readers are done with gt / srt / offl
+#pragma unroll
+        for (int pass = 0; pass < FT_CHUNK / 128; pass++) {
+            const int el = el0 + pass * 128;
+            if (el < n_e) {
+                const int b = b0 + el;
+                float4 g;
+                if constexpr (PAIR) {
+                    const int col16 = rt * 16 + (s8 & 3) * 4;
+                    const float4 go = *reinterpret_cast<const float4 *>(grad_out + (size_t)b * d.out_ld +
+                                                                         (size_t)k * out_w + col16);
+                    const float *sv = saved + ((size_t)k * d.batch + b) * d.rows;
+                    const float4 c0 = *reinterpret_cast<const float4 *>(sv + col16);
+                    const float4 c1 = *reinterpret_cast<const float4 *>(sv + half_rows + col16);
+                    if (s8 < 4) {
+                        g.x = (go.x * c1.x) * bt_act_deriv(d.act, c0.x), g.y = (go.y * c1.y) * bt_act_deriv(d.act, c0.y);
+                        g.z = (go.z * c1.z) * bt_act_deriv(d.act, c0.z), g.w = (go.w * c1.w) * bt_act_deriv(d.act, c0.w);
+                    } else {
+                        g.x = (go.x * c0.x) * bt_act_deriv(d.act, c1.x), g.y = (go.y * c0.y) * bt_act_deriv(d.act, c1.y);
+                        g.z = (go.z * c0.z) * bt_act_deriv(d.act, c1.z), g.w = (go.w * c0.w) * bt_act_deriv(d.act, c1.w);
+                    }
+                } else {
+                    const size_t o = (size_t)b * d.out_ld + (size_t)k * out_w + rt * LDS_RT + s8 * 4;
+                    const float4 go = *reinterpret_cast<const float4 *>(grad_out + o);
+                    const float4 ov = *reinterpret_cast<const float4 *>(out + o);
+                    g.x = go.x * bt_act_deriv(d.act, ov.x), g.y = go.y * bt_act_deriv(d.act, ov.y);
+                    g.z = go.z * bt_act_deriv(d.act, ov.z), g.w = go.w * bt_act_deriv(d.act, ov.w);
+                }
+                *reinterpret_cast<float4 *>(gt + el * LDS_RT + s8 * 4) = g;
+                bsum.x += g.x, bsum.y += g.y, bsum.z += g.z, bsum.w += g.w;
+            }
+        }
+        const uint32_t *go_ = offs + (size_t)c * (d.cols + 1);
+        for (int q = threadIdx.x; q <= d.cols; q += LDS_THREADS) offl[q] = go_[q];
+        const uint32_t total = go_[d.cols];
+        const uint32_t *gs = reinterpret_cast<const uint32_t *>(sorted + (size_t)c * FT_CHUNK * d.nnz);
+        uint32_t *ls = reinterpret_cast<uint32_t *>(srt);
+        for (uint32_t q = threadIdx.x; q < (total + 1) / 2; q += LDS_THREADS) ls[q] = gs[q];
+        __syncthreads();
+        for (int f = grp; f < d.cols; f += LDS_THREADS / 16) {
+            const uint32_t s = offl[f], e = offl[f + 1];
+            if (s == e) continue;
+            float2 a = make_float2(0.0f, 0.0f);
+            uint32_t q = s;
+            for (; q + 4 <= e; q += 4) {
+                const int e0 = srt[q], e1 = srt[q + 1], e2 = srt[q + 2], e3 = srt[q + 3];
+                const float2 v0 = *reinterpret_cast<const float2 *>(gt + e0 * LDS_RT + sub * 2);
+                const float2 v1 = *reinterpret_cast<const float2 *>(gt + e1 * LDS_RT + sub * 2);
+                const float2 v2 = *reinterpret_cast<const float2 *>(gt + e2 * LDS_RT + sub * 2);
+                const float2 v3 = *reinterpret_cast<const float2 *>(gt + e3 * LDS_RT + sub * 2);
+                a.x += v0.x, a.y += v0.y;
+                a.x += v1.x, a.y += v1.y;
+                a.x += v2.x, a.y += v2.y;
+                a.x += v3.x, a.y += v3.y;
+            }
+            for (; q < e; q++) {
+                const float2 v = *reinterpret_cast<const float2 *>(gt + srt[q] * LDS_RT + sub * 2);
+                a.x += v.x, a.y += v.y;
+            }
+            float2 *dst = reinterpret_cast<float2 *>(acc + f * LDS_RT + sub * 2);  // owned by this group only
+            float2 cur = *dst;
+            cur.x += a.x, cur.y += a.y;
+            *dst = cur;
+        }
+    }
+    __syncthreads();
+    float *pw = partial_w + (size_t)cg * d.cols * d.stride;
+    for (int q = threadIdx.x; q < d.cols * 8; q += LDS_THREADS) {
+        const int f = q >> 3, t8 = q & 7;
+        *reinterpret_cast<float4 *>(pw + (size_t)f * d.stride + d.offset + tile_row(PAIR, rt, half_rows, t8 * 4)) =
+            *reinterpret_cast<const float4 *>(acc + f * LDS_RT + t8 * 4);
+    }
+    // bias partial: fixed-order sum over the 128 staging thread groups
+    *reinterpret_cast<float4 *>(gt + el0 * LDS_RT + s8 * 4) = bsum;
+    __syncthreads();
+    if (threadIdx.x < LDS_RT) {
+        float s = 0.0f;
+        for (int i = 0; i < 128; i++) s += gt[i * LDS_RT + threadIdx.x];
+        partial_b[(size_t)cg * d.rows + tile_row(PAIR, rt, half_rows, threadIdx.x)] = s;
+    }
+}
+
+// dw[f][offset + r] = sum_g partial_w[g][f][offset + r] (fixed order); dbias likewise
+__global__ __launch_bounds__(256) void ft_bwd_merge(const float *__restrict__ partial_w,
+                                                    const float *__restrict__ partial_b, float *__restrict__ dw,
+                                                    float *__restrict__ dbias, bt_ft_desc d, int G) {
+    const int rows4 = d.rows / 4;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nw = (long long)d.cols * rows4;
+    if (t < nw) {
+        const int f = (int)(t / rows4), r = (int)(t % rows4) * 4;
+        const size_t o = (size_t)f * d.stride + d.offset + r;
+        float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int g = 0; g < G; g++) {
+            const float4 v = *reinterpret_cast<const float4 *>(partial_w + (size_t)g * d.cols * d.stride + o);
+            s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(dw + o) = s;
+    } else if (dbias && t < nw + d.rows) {
+        const int r = (int)(t - nw);
+        float s = 0.0f;
+        for (int g = 0; g < G; g++) s += partial_b[(size_t)g * d.rows + r];
+        dbias[r] = s;
+    }
+}
+
 struct FtPlan {
+    bool lds_path;
+    int ntiles, G, chunks_per_wg;
+    size_t lds_fwd_bytes, lds_bwd_bytes, off_pw, off_pb;
     int vec;
     int chunks_per_input, nchunks;
     int index_waves;
@@ -361,7 +631,33 @@ int ft_plan(const bt_ft_desc *d, FtPlan *p) {
     p->bias_blocks = bt_div_up((long long)d->n_inputs * d->batch, 256);
     p->off_bpart = o;
     o += bt_align((size_t)p->bias_blocks * d->rows * sizeof(float));
+    // LDS-resident path: 32-row tiles, table tile + staging must fit the 160 KiB LDS
+    p->lds_fwd_bytes = (size_t)(d->cols + 1) * LDS_RT * sizeof(float);
+    p->lds_bwd_bytes = ((size_t)d->cols * LDS_RT + FT_CHUNK * LDS_RT) * sizeof(float) +
+                       (size_t)((d->cols + 2) & ~1) * sizeof(uint32_t) + (size_t)FT_CHUNK * d->nnz * sizeof(uint16_t);
+    p->lds_path = (p->vec == 4) && (d->rows % LDS_RT == 0) && p->lds_bwd_bytes <= 160 * 1024 &&
+                  p->lds_fwd_bytes <= 160 * 1024 && (d->nnz % 2 == 0 || true);
+    p->ntiles = d->rows / LDS_RT;
+    p->G = 1, p->chunks_per_wg = p->nchunks;
+    if (p->lds_path) {
+        int G = 256 / p->ntiles;
+        if (G < 1) G = 1;
+        if (G > p->nchunks) G = p->nchunks;
+        p->chunks_per_wg = bt_div_up(p->nchunks, G);
+        p->G = bt_div_up(p->nchunks, p->chunks_per_wg);
+        p->off_pw = o;
+        o += bt_align((size_t)p->G * d->cols * d->stride * sizeof(float));
+        p->off_pb = o;
+        o += bt_align((size_t)p->G * d->rows * sizeof(float));
+    }
     p->total = o;
+    return BT_OK;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    BT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes));
     return BT_OK;
 }
 
@@ -381,6 +677,38 @@ int bt_ft_forward(void *stream, const bt_ft_desc *d, const float *w, const float
     dim3 grid(bt_div_up(total, 256)), block(256);
     hipStream_t s = bt_stream(stream);
     const int32_t *i0 = idx[0], *i1 = d->n_inputs > 1 ? idx[1] : idx[0];
+    FtPlan p;
+    if (int rc = ft_plan(d, &p)) return rc;
+    if (p.lds_path && !force_generic()) {
+        const long long E = (long long)d->n_inputs * d->batch;
+        int G = 256 / p.ntiles;
+        if (G < 1) G = 1;
+        long long epw = (E + G - 1) / G;
+        epw = (epw + 63) / 64 * 64;  // whole passes of 16 waves x 4 entries
+        G = (int)((E + epw - 1) / epw);
+        const int nreg = (d->nnz + 15) / 16;
+        dim3 lgrid(p.ntiles * G), lblock(LDS_THREADS);
+#define FWD_LDS(PAIR, NREG)                                                                                     \
+    do {                                                                                                        \
+        if (int rc = set_lds(ft_fwd_lds<PAIR, NREG>, p.lds_fwd_bytes)) return rc;                               \
+        BT_LAUNCH(BTK_FT_FWD_LDS, s, (ft_fwd_lds<PAIR, NREG>), lgrid, lblock, p.lds_fwd_bytes, w, bias, i0, i1, out, \
+                  saved, *d, p.ntiles, (int)epw);                                                               \
+    } while (0)
+        if (d->pairwise) {
+            if (nreg == 1) FWD_LDS(true, 1);
+            else if (nreg == 2) FWD_LDS(true, 2);
+            else if (nreg == 3) FWD_LDS(true, 3);
+            else FWD_LDS(true, 4);
+        } else {
+            if (nreg == 1) FWD_LDS(false, 1);
+            else if (nreg == 2) FWD_LDS(false, 2);
+            else if (nreg == 3) FWD_LDS(false, 3);
+            else FWD_LDS(false, 4);
+        }
+#undef FWD_LDS
+        BT_LAUNCH_CHECK();
+        return BT_OK;
+    }
     if (vec == 4) {
         if (d->pairwise)
             BT_LAUNCH(BTK_FT_FWD_GENERIC, s, (ft_fwd_generic<4, true>), grid, block, 0, w, bias, i0, i1, out, saved, *d);
@@ -427,6 +755,25 @@ int bt_ft_backward(void *stream, const bt_ft_desc *d, const int32_t *const *idx,
         BT_LAUNCH(BTK_FT_INDEX, s, ft_index_kernel, dim3(p.nchunks), dim3(threads), lds, i0, i1, d->batch, d->nnz, d->cols,
                            p.chunks_per_input, p.fbits, sorted, offs);
         BT_LAUNCH_CHECK();
+    }
+    if (p.lds_path && !force_generic()) {
+        float *pw = reinterpret_cast<float *>(ws + p.off_pw), *pb = reinterpret_cast<float *>(ws + p.off_pb);
+        dim3 grid(p.ntiles * p.G), block(LDS_THREADS);
+        if (d->pairwise) {
+            if (int rc = set_lds(ft_bwd_lds<true>, p.lds_bwd_bytes)) return rc;
+            BT_LAUNCH(BTK_FT_BWD_LDS, s, (ft_bwd_lds<true>), grid, block, p.lds_bwd_bytes, grad_out, out, saved, sorted,
+                      offs, pw, pb, *d, p.ntiles, p.chunks_per_input, p.chunks_per_wg);
+        } else {
+            if (int rc = set_lds(ft_bwd_lds<false>, p.lds_bwd_bytes)) return rc;
+            BT_LAUNCH(BTK_FT_BWD_LDS, s, (ft_bwd_lds<false>), grid, block, p.lds_bwd_bytes, grad_out, out, saved, sorted,
+                      offs, pw, pb, *d, p.ntiles, p.chunks_per_input, p.chunks_per_wg);
+        }
+        BT_LAUNCH_CHECK();
+        if (d->rows != d->stride) BT_HIP(hipMemsetAsync(dw, 0, (size_t)d->stride * d->cols * sizeof(float), s));
+        const long long n = (long long)d->cols * (d->rows / 4) + d->rows;
+        BT_LAUNCH(BTK_FT_BWD_MERGE, s, ft_bwd_merge, dim3(bt_div_up(n, 256)), dim3(256), 0, pw, pb, dw, dbias, *d, p.G);
+        BT_LAUNCH_CHECK();
+        return BT_OK;
     }
     {
         const int out_w = d->pairwise ? d->rows / 2 : d->rows;

@@ -72,8 +72,22 @@ FT_CASES = [
 ]
 
 
+@pytest.fixture(params=["auto", "generic"])
+def ft_path(request, monkeypatch):
+    """auto = LDS-resident kernels where the shape allows; generic = the any-shape kernels on every shape"""
+    monkeypatch.setenv("BT_FT_FORCE_GENERIC", "1" if request.param == "generic" else "0")
+    return request.param
+
+
+FT_CASES += [
+    (1100, 64, 768, 32, "crelu", 1, 2, 64, 0),       # LDS path, pairwise (16+16 row tiles), >4 chunks, tail
+    (2049, 32, 300, 20, "screlu", 0, 1, 96, 32),     # LDS path with stride/offset, single input, nnz 20
+    (600, 256, 147, 49, "relu", 0, 2, 256, 0),       # LDS path, nnz 49 -> 4 index registers
+]
+
+
 @pytest.mark.parametrize("batch,rows,cols,nnz,act,pairwise,n_inputs,stride,offset", FT_CASES)
-def test_ft_forward_backward_vs_oracle(batch, rows, cols, nnz, act, pairwise, n_inputs, stride, offset):
+def test_ft_forward_backward_vs_oracle(ft_path, batch, rows, cols, nnz, act, pairwise, n_inputs, stride, offset):
     rng = np.random.default_rng(batch * 7 + rows)
     out_w = rows // 2 if pairwise else rows
     d = lib.FtDesc(batch=batch, rows=rows, cols=cols, stride=stride, offset=offset, nnz=nnz, act=lib.ACT[act],
