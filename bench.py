@@ -103,7 +103,7 @@ def algorithmic_bytes(kernel, B, nbar, P=2, H=1024, N=32, F=768, K=2048, O=8):
         "ft_bwd_make_g": P * B * 3 * H * 4,                          # dout, out -> g
         "ft_bwd_lds": ft_bwd, "ft_bwd_merge": 2 * F * H * 4,
         "ft_index_kernel": P * B * N * 4 + P * B * N * 2,
-        "dense_fwd_kernel": dense_pass, "dense_bwd_dx_kernel": dense_pass, "dense_bwd_dw_kernel": dense_pass,
+        "dense_fwd_kernel": dense_pass, "dense_fwd_small": dense_pass, "dense_bwd_small": 2 * dense_pass, "dense_bwd_dx_kernel": dense_pass, "dense_bwd_dw_kernel": dense_pass,
         "adamw_kernel": 28 * (F * H + H + K * O + O),
         "sigmoid_mse_kernel": 5 * B * 4,
     }

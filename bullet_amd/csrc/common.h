@@ -48,6 +48,8 @@ enum BtKernelId {
     BTK_COLSUM_PARTIAL,
     BTK_COLSUM_FINAL,
     BTK_DENSE_FWD,
+    BTK_DENSE_FWD_SMALL,
+    BTK_DENSE_BWD_SMALL,
     BTK_DENSE_BWD_DX,
     BTK_DENSE_BWD_DW,
     BTK_SUM_PARTIALS,

@@ -111,12 +111,26 @@ __global__ __launch_bounds__(256) void dense_bwd_dw_kernel(const float *__restri
         for (int r = threadIdx.x; r < rows; r += blockDim.x) part_b[(size_t)blockIdx.y * rows + r] = accb[r];
 }
 
-__global__ void sum_partials_kernel(const float *__restrict__ part, int nparts, size_t n, float *__restrict__ out) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
+// out[t] = sum_p part[p][t] in a fixed order: 32 elements x 8 partial-slices per workgroup; each slice
+// sums its contiguous share of the partials sequentially, the 8 slice sums are then added in order.
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float *__restrict__ part, int nparts, size_t n,
+                                                           float *__restrict__ out) {
+    __shared__ float red[8][32];
+    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const size_t t = (size_t)blockIdx.x * 32 + el;
+    const int per = (nparts + 7) / 8;
+    const int p0 = sl * per, p1 = min(nparts, p0 + per);
     float s = 0.0f;
-    for (int p = 0; p < nparts; p++) s += part[(size_t)p * n + t];
-    out[t] = s;
+    if (t < n)
+        for (int p = p0; p < p1; p++) s += part[(size_t)p * n + t];
+    red[sl][el] = s;
+    __syncthreads();
+    if (sl == 0 && t < n) {
+        float r = red[0][el];
+#pragma unroll
+        for (int i = 1; i < 8; i++) r += red[i][el];
+        out[t] = r;
+    }
 }
 
 // ------------------------------------------------------------------ loss
@@ -194,6 +208,125 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamTable tab, const float *
     }
 }
 
+
+// ------------------------------------------------------------------ small-head fast paths
+// Forward for layers whose whole weight matrix fits in LDS (config 2: 8 x 2048 x 4 B = 64 KiB):
+// W is transposed into LDS once per workgroup, then one wave per position streams x with float4
+// loads (HBM-bound on x) and reads the selected bucket's rows from LDS.
+constexpr int DF_THREADS = 1024;
+
+template <int NX>
+__global__ __launch_bounds__(DF_THREADS) void dense_fwd_small(const float *__restrict__ w,
+                                                              const float *__restrict__ bias,
+                                                              const float *__restrict__ x,
+                                                              const int32_t *__restrict__ bucket,
+                                                              float *__restrict__ y, bt_dense_desc d, int pos_per_wg) {
+    extern __shared__ float wt[];  // [rows][in + 4]
+    const int rows = d.out * d.buckets;
+    const int ldw = d.in + 4;
+    for (int q = threadIdx.x; q < rows * d.in; q += DF_THREADS) {
+        const int i = q / rows, r = q - i * rows;
+        wt[r * ldw + i] = w[q];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b_end = min(d.batch, (int)(blockIdx.x + 1) * pos_per_wg);
+    for (int b = blockIdx.x * pos_per_wg + wave; b < b_end; b += DF_THREADS / 64) {
+        const int base = (d.buckets > 1) ? bucket[b] * d.out : 0;
+        const float4 *xb = reinterpret_cast<const float4 *>(x + (size_t)b * d.in);
+        float4 xv[NX];
+#pragma unroll
+        for (int j = 0; j < NX; j++) xv[j] = xb[j * 64 + lane];
+        for (int o = 0; o < d.out; o++) {
+            const float4 *wr = reinterpret_cast<const float4 *>(wt + (base + o) * ldw);
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NX; j++) {
+                const float4 w4 = wr[j * 64 + lane];
+                acc += xv[j].x * w4.x;
+                acc += xv[j].y * w4.y;
+                acc += xv[j].z * w4.z;
+                acc += xv[j].w * w4.w;
+            }
+            const float sum = wave_sum(acc);
+            if (lane == 0) y[(size_t)b * d.out + o] = bt_act_fwd(d.act, sum + bias[base + o]);
+        }
+    }
+}
+
+// Backward for out == 1 heads (one selected row per position): every thread owns 4 input columns for
+// ALL bucket rows in registers; the bucket select becomes a wave-uniform multiplier (gz or 0), so dW,
+// dbias and dX come out of one pass over x with no LDS and no atomics. Positions are visited in
+// ascending order inside a workgroup, workgroup partials are merged in order => deterministic.
+template <int ROWS>
+__global__ __launch_bounds__(256) void dense_bwd_small(const float *__restrict__ w, const float *__restrict__ x,
+                                                       const int32_t *__restrict__ bucket,
+                                                       const float *__restrict__ y,
+                                                       const float *__restrict__ grad_y,
+                                                       float *__restrict__ part_w, float *__restrict__ part_b,
+                                                       float *__restrict__ grad_x, bt_dense_desc d, int range) {
+    const int rows = d.buckets;  // out == 1
+    const int in4 = d.in >> 2;
+    const int c4 = blockIdx.x * 256 + threadIdx.x;
+    const bool active = c4 < in4;
+    float4 wr[ROWS], acc[ROWS];
+    float accb[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        acc[r] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        accb[r] = 0.0f;
+        wr[r] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (active && r < rows) {
+            const float *wc = w + (size_t)rows * (c4 * 4) + r;
+            wr[r] = make_float4(wc[0], wc[rows], wc[2 * rows], wc[3 * rows]);
+        }
+    }
+    const int b0 = blockIdx.y * range, b1 = min(d.batch, b0 + range);
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    float4 *gx4 = reinterpret_cast<float4 *>(grad_x);
+#pragma unroll 4
+    for (int b = b0; b < b1; b++) {
+        const int bk = (d.buckets > 1) ? bucket[b] : 0;
+        const float gz = grad_y[b] * bt_act_deriv(d.act, y[b]);
+        const float4 xv = active ? x4[(size_t)b * in4 + c4] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float4 gx = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const float m = (r == bk) ? gz : 0.0f;  // SelectPad: zeros outside the selected row
+            acc[r].x += m * xv.x, acc[r].y += m * xv.y, acc[r].z += m * xv.z, acc[r].w += m * xv.w;
+            gx.x += m * wr[r].x, gx.y += m * wr[r].y, gx.z += m * wr[r].z, gx.w += m * wr[r].w;
+            accb[r] += m;
+        }
+        if (grad_x && active) gx4[(size_t)b * in4 + c4] = gx;
+    }
+    if (active) {
+        float *pw = part_w + (size_t)blockIdx.y * rows * d.in + (size_t)rows * (c4 * 4);
+#pragma unroll
+        for (int r = 0; r < ROWS; r++)
+            if (r < rows) pw[r] = acc[r].x, pw[rows + r] = acc[r].y, pw[2 * rows + r] = acc[r].z, pw[3 * rows + r] = acc[r].w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+        for (int r = 0; r < ROWS; r++)
+            if (r < rows) part_b[(size_t)blockIdx.y * rows + r] = accb[r];
+    }
+}
+
+constexpr int DBS_RANGE = 64;  // positions per workgroup in dense_bwd_small
+
+bool dense_fwd_small_ok(const bt_dense_desc *d) {
+    const int rows = d->out * d->buckets;
+    return d->in % 256 == 0 && d->in / 256 <= 8 && (size_t)rows * (d->in + 4) * sizeof(float) <= 96 * 1024;
+}
+bool dense_bwd_small_ok(const bt_dense_desc *d) { return d->out == 1 && d->buckets <= 16 && d->in % 4 == 0; }
+
+template <typename K>
+int dense_set_lds(K kernel, size_t bytes) {
+    BT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes));
+    return BT_OK;
+}
+
 int dense_validate(const bt_dense_desc *d, const char *who) {
     BT_REQUIRE(d, "%s: null descriptor", who);
     BT_REQUIRE(d->batch > 0 && d->in > 0 && d->out > 0 && d->buckets > 0, "%s: Mismatched sizes! (non-positive dim)", who);
@@ -212,6 +345,27 @@ int bt_dense_forward(void *stream, const bt_dense_desc *d, const float *w, const
     if (int rc = dense_validate(d, "bt_dense_forward")) return rc;
     BT_REQUIRE(w && bias && x && y, "bt_dense_forward: null pointer");
     BT_REQUIRE(d->buckets == 1 || bucket, "bt_dense_forward: bucketed layer needs bucket indices");
+    if (dense_fwd_small_ok(d)) {
+        hipStream_t s = bt_stream(stream);
+        const int rows = d->out * d->buckets;
+        const size_t lds = (size_t)rows * (d->in + 4) * sizeof(float);
+        int nwg = bt_div_up(d->batch, 64);
+        if (nwg > 256) nwg = 256;
+        const int ppw = bt_div_up(d->batch, nwg);
+        nwg = bt_div_up(d->batch, ppw);
+#define DFS(NX)                                                                                              \
+    case NX:                                                                                                 \
+        if (int rc = dense_set_lds(dense_fwd_small<NX>, lds)) return rc;                                     \
+        BT_LAUNCH(BTK_DENSE_FWD_SMALL, s, (dense_fwd_small<NX>), dim3(nwg), dim3(DF_THREADS), lds, w, bias, x, bucket, \
+                  y, *d, ppw);                                                                               \
+        break;
+        switch (d->in / 256) {
+            DFS(1) DFS(2) DFS(3) DFS(4) DFS(5) DFS(6) DFS(7) DFS(8)
+        }
+#undef DFS
+        BT_LAUNCH_CHECK();
+        return BT_OK;
+    }
     BT_LAUNCH(BTK_DENSE_FWD, bt_stream(stream), dense_fwd_kernel, dim3(bt_div_up(d->batch, 4)), dim3(256), 0, w, bias, x,
                        bucket, y, *d);
     BT_LAUNCH_CHECK();
@@ -221,7 +375,7 @@ int bt_dense_forward(void *stream, const bt_dense_desc *d, const float *w, const
 size_t bt_dense_backward_workspace_bytes(const bt_dense_desc *d) {
     if (dense_validate(d, "bt_dense_backward_workspace_bytes")) return 0;
     const int rows = d->out * d->buckets;
-    const int nr = bt_div_up(d->batch, DW_RANGE);
+    const int nr = dense_bwd_small_ok(d) ? bt_div_up(d->batch, DBS_RANGE) : bt_div_up(d->batch, DW_RANGE);
     return bt_align((size_t)nr * rows * d->in * sizeof(float)) + bt_align((size_t)nr * rows * sizeof(float));
 }
 
@@ -234,10 +388,31 @@ int bt_dense_backward(void *stream, const bt_dense_desc *d, const float *w, cons
     BT_REQUIRE(workspace_bytes >= bt_dense_backward_workspace_bytes(d), "bt_dense_backward: workspace too small");
     hipStream_t s = bt_stream(stream);
     const int rows = d->out * d->buckets;
-    const int nr = bt_div_up(d->batch, DW_RANGE);
+    const bool small = dense_bwd_small_ok(d);
+    const int nr = small ? bt_div_up(d->batch, DBS_RANGE) : bt_div_up(d->batch, DW_RANGE);
     float *part_w = static_cast<float *>(workspace);
     float *part_b = reinterpret_cast<float *>(static_cast<char *>(workspace) +
                                               bt_align((size_t)nr * rows * d->in * sizeof(float)));
+    if (small) {
+        dim3 grid(bt_div_up(d->in / 4, 256), nr), block(256);
+#define DBS(R)                                                                                                   \
+    BT_LAUNCH(BTK_DENSE_BWD_SMALL, s, (dense_bwd_small<R>), grid, block, 0, w, x, bucket, y, grad_y, part_w, part_b, \
+              grad_x, *d, DBS_RANGE)
+        if (rows <= 1) DBS(1);
+        else if (rows <= 2) DBS(2);
+        else if (rows <= 4) DBS(4);
+        else if (rows <= 8) DBS(8);
+        else DBS(16);
+#undef DBS
+        BT_LAUNCH_CHECK();
+        const size_t nw = (size_t)rows * d->in;
+        BT_LAUNCH(BTK_SUM_PARTIALS, s, sum_partials_kernel, dim3(bt_div_up(nw, 32)), dim3(256), 0, part_w, nr, nw, dw);
+        BT_LAUNCH_CHECK();
+        BT_LAUNCH(BTK_SUM_PARTIALS, s, sum_partials_kernel, dim3(bt_div_up(rows, 32)), dim3(256), 0, part_b, nr,
+                  (size_t)rows, dbias);
+        BT_LAUNCH_CHECK();
+        return BT_OK;
+    }
     if (grad_x) {
         BT_LAUNCH(BTK_DENSE_BWD_DX, s, dense_bwd_dx_kernel, dim3(bt_div_up((long long)d->batch * d->in, 256)), dim3(256), 0, w,
                            bucket, y, grad_y, grad_x, *d);
@@ -248,9 +423,9 @@ int bt_dense_backward(void *stream, const bt_dense_desc *d, const float *w, cons
                        grad_y, part_w, part_b, *d);
     BT_LAUNCH_CHECK();
     const size_t nw = (size_t)rows * d->in;
-    BT_LAUNCH(BTK_SUM_PARTIALS, s, sum_partials_kernel, dim3(bt_div_up(nw, 256)), dim3(256), 0, part_w, nr, nw, dw);
+    BT_LAUNCH(BTK_SUM_PARTIALS, s, sum_partials_kernel, dim3(bt_div_up(nw, 32)), dim3(256), 0, part_w, nr, nw, dw);
     BT_LAUNCH_CHECK();
-    BT_LAUNCH(BTK_SUM_PARTIALS, s, sum_partials_kernel, dim3(bt_div_up(rows, 256)), dim3(256), 0, part_b, nr, (size_t)rows,
+    BT_LAUNCH(BTK_SUM_PARTIALS, s, sum_partials_kernel, dim3(bt_div_up(rows, 32)), dim3(256), 0, part_b, nr, (size_t)rows,
                        dbias);
     BT_LAUNCH_CHECK();
     return BT_OK;

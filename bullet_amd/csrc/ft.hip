@@ -336,7 +336,7 @@ constexpr int LDS_THREADS = 1024;
 
 template <int N>
 __device__ __forceinline__ int row_share(int v) {  // broadcast lane N of each 16-lane row (DPP, no LDS traffic)
-    return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xF, 0xF, false);
+    return __builtin_amdgcn_update_dpp(v, v, 0x150 + N, 0xF, 0xF, true);
 }
 
 __device__ __forceinline__ int tile_row(bool pair, int rt, int half_rows, int local4) {
@@ -345,14 +345,29 @@ __device__ __forceinline__ int tile_row(bool pair, int rt, int half_rows, int lo
     return (local4 < 16) ? rt * 16 + local4 : half_rows + rt * 16 + (local4 - 16);
 }
 
-template <int N>
-__device__ __forceinline__ void fwd_step(const float *wl, int reg, int base, int maxcnt, int sub, float2 &acc) {
-    if (base + N < maxcnt) {  // wave-uniform
-        const int f = row_share<N>(reg);
-        const float2 v = *reinterpret_cast<const float2 *>(wl + f * LDS_RT + sub * 2);
-        acc.x += v.x;
-        acc.y += v.y;
-    }
+// 8 gathers issued back to back (independent LDS reads in flight), then 8 ordered adds.
+template <int N0>
+__device__ __forceinline__ void fwd_block8(const float *wl, int reg, int sub, float2 &acc) {
+    const int f0 = row_share<N0 + 0>(reg), f1 = row_share<N0 + 1>(reg), f2 = row_share<N0 + 2>(reg),
+              f3 = row_share<N0 + 3>(reg), f4 = row_share<N0 + 4>(reg), f5 = row_share<N0 + 5>(reg),
+              f6 = row_share<N0 + 6>(reg), f7 = row_share<N0 + 7>(reg);
+    const float *base = wl + sub * 2;
+    const float2 v0 = *reinterpret_cast<const float2 *>(base + f0 * LDS_RT);
+    const float2 v1 = *reinterpret_cast<const float2 *>(base + f1 * LDS_RT);
+    const float2 v2 = *reinterpret_cast<const float2 *>(base + f2 * LDS_RT);
+    const float2 v3 = *reinterpret_cast<const float2 *>(base + f3 * LDS_RT);
+    const float2 v4 = *reinterpret_cast<const float2 *>(base + f4 * LDS_RT);
+    const float2 v5 = *reinterpret_cast<const float2 *>(base + f5 * LDS_RT);
+    const float2 v6 = *reinterpret_cast<const float2 *>(base + f6 * LDS_RT);
+    const float2 v7 = *reinterpret_cast<const float2 *>(base + f7 * LDS_RT);
+    acc.x += v0.x, acc.y += v0.y;
+    acc.x += v1.x, acc.y += v1.y;
+    acc.x += v2.x, acc.y += v2.y;
+    acc.x += v3.x, acc.y += v3.y;
+    acc.x += v4.x, acc.y += v4.y;
+    acc.x += v5.x, acc.y += v5.y;
+    acc.x += v6.x, acc.y += v6.y;
+    acc.x += v7.x, acc.y += v7.y;
 }
 
 template <bool PAIR, int NREG>
@@ -378,25 +393,42 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
     const int row = tile_row(PAIR, rt, half_rows, sub * 2);
     float2 bv = make_float2(0.0f, 0.0f);
     if (bias) bv = *reinterpret_cast<const float2 *>(bias + row);
-    const long long E = (long long)d.n_inputs * d.batch;
-    const long long e_begin = (long long)grp * entries_per_wg;
-    const long long e_end = min(E, e_begin + entries_per_wg);
+    // entries e = k*batch + b as 32-bit ints (host checks n_inputs*batch < 2^31); n_inputs <= 2, so the
+    // (k, b) split is a compare + subtract -- no integer division in the hot loop
+    const int E = d.n_inputs * d.batch;
+    const int e_begin = grp * entries_per_wg;
+    const int e_end = min(E, e_begin + entries_per_wg);
     const int out_w = PAIR ? half_rows : d.rows;
 
-    for (long long eb = e_begin + wave * 4; eb < e_end; eb += (LDS_THREADS / 64) * 4) {
-        const long long e = eb + eslot;
+    // raw index registers of the NEXT iteration are loaded while the current one is being summed
+    auto load_idx = [&](int eb2, int(&r)[NREG]) {
+        const int e2 = eb2 + eslot;
+        const bool lv = e2 < e_end;
+        const int k2 = (lv && e2 >= d.batch) ? 1 : 0;
+        const int b2 = lv ? e2 - k2 * d.batch : 0;
+        const int32_t *ip = (k2 == 0 ? idx0 : idx1) + (size_t)b2 * d.nnz;
+#pragma unroll
+        for (int q = 0; q < NREG; q++) {
+            const int p = q * 16 + sub;
+            r[q] = (lv && p < d.nnz) ? ip[p] : -1;
+        }
+    };
+    int nxt[NREG];
+    load_idx(e_begin + wave * 4, nxt);
+    for (int eb = e_begin + wave * 4; eb < e_end; eb += (LDS_THREADS / 64) * 4) {
+        const int e = eb + eslot;
         const bool live = e < e_end;
-        const int k = live ? (int)(e / d.batch) : 0;
-        const int b = live ? (int)(e % d.batch) : 0;
-        const int32_t *ip = (k == 0 ? idx0 : idx1) + (size_t)b * d.nnz;
+        const int k = (live && e >= d.batch) ? 1 : 0;
+        const int b = live ? e - k * d.batch : 0;
         int reg[NREG];
+#pragma unroll
+        for (int q = 0; q < NREG; q++) reg[q] = nxt[q];
+        load_idx(eb + (LDS_THREADS / 64) * 4, nxt);
         int nvalid = d.nnz;
 #pragma unroll
         for (int q = NREG - 1; q >= 0; q--) {
             const int p = q * 16 + sub;
-            int j = -1;
-            if (live && p < d.nnz) j = ip[p];
-            reg[q] = j;
+            const int j = reg[q];
             const bool inval = (p >= d.nnz) || j < 0 || j >= d.cols;
             const unsigned m = (unsigned)((__ballot(inval) >> (eslot * 16)) & 0xFFFFull);
             if (m) nvalid = q * 16 + __ffs((int)m) - 1;  // descending q: the smallest position wins
@@ -410,23 +442,9 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
         float2 acc = make_float2(0.0f, 0.0f);
 #pragma unroll
         for (int q = 0; q < NREG; q++) {
-            const int base = q * 16;
-            fwd_step<0>(wl, reg[q], base, maxcnt, sub, acc);
-            fwd_step<1>(wl, reg[q], base, maxcnt, sub, acc);
-            fwd_step<2>(wl, reg[q], base, maxcnt, sub, acc);
-            fwd_step<3>(wl, reg[q], base, maxcnt, sub, acc);
-            fwd_step<4>(wl, reg[q], base, maxcnt, sub, acc);
-            fwd_step<5>(wl, reg[q], base, maxcnt, sub, acc);
-            fwd_step<6>(wl, reg[q], base, maxcnt, sub, acc);
-            fwd_step<7>(wl, reg[q], base, maxcnt, sub, acc);
-            fwd_step<8>(wl, reg[q], base, maxcnt, sub, acc);
-            fwd_step<9>(wl, reg[q], base, maxcnt, sub, acc);
-            fwd_step<10>(wl, reg[q], base, maxcnt, sub, acc);
-            fwd_step<11>(wl, reg[q], base, maxcnt, sub, acc);
-            fwd_step<12>(wl, reg[q], base, maxcnt, sub, acc);
-            fwd_step<13>(wl, reg[q], base, maxcnt, sub, acc);
-            fwd_step<14>(wl, reg[q], base, maxcnt, sub, acc);
-            fwd_step<15>(wl, reg[q], base, maxcnt, sub, acc);
+            // wave-uniform skips at 8-slot granularity; masked slots inside a block read the zero row
+            if (q * 16 < maxcnt) fwd_block8<0>(wl, reg[q], sub, acc);
+            if (q * 16 + 8 < maxcnt) fwd_block8<8>(wl, reg[q], sub, acc);
         }
         float2 c = make_float2(bt_act_fwd(d.act, acc.x + bv.x), bt_act_fwd(d.act, acc.y + bv.y));
         if constexpr (PAIR) {
@@ -456,8 +474,8 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
                                                           int chunks_per_input, int chunks_per_wg) {
     extern __shared__ float lds_f[];
     float *acc = lds_f;                                   // [cols][32]
-    float *gt = acc + (size_t)d.cols * LDS_RT;            // [FT_CHUNK][32]
-    uint32_t *offl = reinterpret_cast<uint32_t *>(gt + FT_CHUNK * LDS_RT);  // [cols + 1]
+    float *gt = acc + (size_t)d.cols * LDS_RT;            // [FT_CHUNK + 1][32], last row = zeros (padding target)
+    uint32_t *offl = reinterpret_cast<uint32_t *>(gt + (FT_CHUNK + 1) * LDS_RT);  // [cols + 1]
     uint16_t *srt = reinterpret_cast<uint16_t *>(offl + ((d.cols + 1 + 1) & ~1));  // [FT_CHUNK * nnz]
     const int rt = blockIdx.x % ntiles, cg = blockIdx.x / ntiles;
     const int half_rows = d.rows / 2;
@@ -465,29 +483,67 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
     const int out_w = PAIR ? half_rows : d.rows;
 
     for (int q = threadIdx.x; q < d.cols * LDS_RT; q += LDS_THREADS) acc[q] = 0.0f;
+    if (threadIdx.x < LDS_RT) gt[FT_CHUNK * LDS_RT + threadIdx.x] = 0.0f;
 
     const int s8 = threadIdx.x & 7, el0 = threadIdx.x >> 3;  // staging role: 128 entries x 8 float4 per pass
     const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;  // reduce role: 64 groups of 16 lanes (float2)
     float4 bsum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int c_lo = cg * chunks_per_wg, c_hi = min(nchunks, c_lo + chunks_per_wg);
-    for (int c = c_lo; c < c_hi; c++) {
+    // Staging registers: the NEXT chunk's global loads are issued before the current chunk's LDS reduction
+    // and consumed after it, so HBM latency overlaps the reduction without a second LDS buffer.
+    constexpr int NPASS = FT_CHUNK / 128;
+    float4 r_go[NPASS], r_a[NPASS], r_b[NPASS];
+    uint32_t r_srt[8], r_off[2];
+    const int srt_words = FT_CHUNK * d.nnz / 2;  // <= 8 * LDS_THREADS (nnz <= 64)
+    auto prefetch = [&](int c) {
         const int k = c / chunks_per_input, cb = c % chunks_per_input;
         const int b0 = cb * FT_CHUNK;
         const int n_e = min(FT_CHUNK, d.batch - b0);
-        __syncthreads();  // previous chunk's readers are done with gt / srt / offl
 #pragma unroll
-        for (int pass = 0; pass < FT_CHUNK / 128; pass++) {
+        for (int pass = 0; pass < NPASS; pass++) {
             const int el = el0 + pass * 128;
+            r_go[pass] = r_a[pass] = r_b[pass] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (el < n_e) {
                 const int b = b0 + el;
-                float4 g;
                 if constexpr (PAIR) {
                     const int col16 = rt * 16 + (s8 & 3) * 4;
-                    const float4 go = *reinterpret_cast<const float4 *>(grad_out + (size_t)b * d.out_ld +
-                                                                         (size_t)k * out_w + col16);
+                    r_go[pass] = *reinterpret_cast<const float4 *>(grad_out + (size_t)b * d.out_ld + (size_t)k * out_w + col16);
                     const float *sv = saved + ((size_t)k * d.batch + b) * d.rows;
-                    const float4 c0 = *reinterpret_cast<const float4 *>(sv + col16);
-                    const float4 c1 = *reinterpret_cast<const float4 *>(sv + half_rows + col16);
+                    r_a[pass] = *reinterpret_cast<const float4 *>(sv + col16);
+                    r_b[pass] = *reinterpret_cast<const float4 *>(sv + half_rows + col16);
+                } else {
+                    const size_t o = (size_t)b * d.out_ld + (size_t)k * out_w + rt * LDS_RT + s8 * 4;
+                    r_go[pass] = *reinterpret_cast<const float4 *>(grad_out + o);
+                    r_a[pass] = *reinterpret_cast<const float4 *>(out + o);
+                }
+            }
+        }
+        const uint32_t *go_ = offs + (size_t)c * (d.cols + 1);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int q = threadIdx.x + i * LDS_THREADS;
+            r_off[i] = (q <= d.cols) ? go_[q] : 0u;
+        }
+        const uint32_t *gs = reinterpret_cast<const uint32_t *>(sorted + (size_t)c * FT_CHUNK * d.nnz);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int q = threadIdx.x + i * LDS_THREADS;
+            r_srt[i] = (q < srt_words) ? gs[q] : 0u;
+        }
+    };
+    if (c_lo < c_hi) prefetch(c_lo);
+    for (int c = c_lo; c < c_hi; c++) {
+        const int cb = c % chunks_per_input;
+        const int n_e = min(FT_CHUNK, d.batch - cb * FT_CHUNK);
+        __syncthreads();  // previous chunk's readers are done with gt / srt / offl
+#pragma unroll
+        for (int pass = 0; pass < NPASS; pass++) {
+            const int el = el0 + pass * 128;
+            if (el < n_e) {
+                const float4 go = r_go[pass];
+                float4 g;
+                if constexpr (PAIR) {
+                    const float4 c0 = r_a[pass], c1 = r_b[pass];
                     if (s8 < 4) {
                         g.x = (go.x * c1.x) * bt_act_deriv(d.act, c0.x), g.y = (go.y * c1.y) * bt_act_deriv(d.act, c0.y);
                         g.z = (go.z * c1.z) * bt_act_deriv(d.act, c0.z), g.w = (go.w * c1.w) * bt_act_deriv(d.act, c0.w);
@@ -496,9 +552,7 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
                         g.z = (go.z * c0.z) * bt_act_deriv(d.act, c1.z), g.w = (go.w * c0.w) * bt_act_deriv(d.act, c1.w);
                     }
                 } else {
-                    const size_t o = (size_t)b * d.out_ld + (size_t)k * out_w + rt * LDS_RT + s8 * 4;
-                    const float4 go = *reinterpret_cast<const float4 *>(grad_out + o);
-                    const float4 ov = *reinterpret_cast<const float4 *>(out + o);
+                    const float4 ov = r_a[pass];
                     g.x = go.x * bt_act_deriv(d.act, ov.x), g.y = go.y * bt_act_deriv(d.act, ov.y);
                     g.z = go.z * bt_act_deriv(d.act, ov.z), g.w = go.w * bt_act_deriv(d.act, ov.w);
                 }
@@ -506,32 +560,35 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
                 bsum.x += g.x, bsum.y += g.y, bsum.z += g.z, bsum.w += g.w;
             }
         }
-        const uint32_t *go_ = offs + (size_t)c * (d.cols + 1);
-        for (int q = threadIdx.x; q <= d.cols; q += LDS_THREADS) offl[q] = go_[q];
-        const uint32_t total = go_[d.cols];
-        const uint32_t *gs = reinterpret_cast<const uint32_t *>(sorted + (size_t)c * FT_CHUNK * d.nnz);
-        uint32_t *ls = reinterpret_cast<uint32_t *>(srt);
-        for (uint32_t q = threadIdx.x; q < (total + 1) / 2; q += LDS_THREADS) ls[q] = gs[q];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int q = threadIdx.x + i * LDS_THREADS;
+            if (q <= d.cols) offl[q] = r_off[i];
+        }
+        {
+            uint32_t *ls = reinterpret_cast<uint32_t *>(srt);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int q = threadIdx.x + i * LDS_THREADS;
+                if (q < srt_words) ls[q] = r_srt[i];
+            }
+        }
         __syncthreads();
+        if (c + 1 < c_hi) prefetch(c + 1);
         for (int f = grp; f < d.cols; f += LDS_THREADS / 16) {
             const uint32_t s = offl[f], e = offl[f + 1];
             if (s == e) continue;
             float2 a = make_float2(0.0f, 0.0f);
-            uint32_t q = s;
-            for (; q + 4 <= e; q += 4) {
-                const int e0 = srt[q], e1 = srt[q + 1], e2 = srt[q + 2], e3 = srt[q + 3];
-                const float2 v0 = *reinterpret_cast<const float2 *>(gt + e0 * LDS_RT + sub * 2);
-                const float2 v1 = *reinterpret_cast<const float2 *>(gt + e1 * LDS_RT + sub * 2);
-                const float2 v2 = *reinterpret_cast<const float2 *>(gt + e2 * LDS_RT + sub * 2);
-                const float2 v3 = *reinterpret_cast<const float2 *>(gt + e3 * LDS_RT + sub * 2);
-                a.x += v0.x, a.y += v0.y;
-                a.x += v1.x, a.y += v1.y;
-                a.x += v2.x, a.y += v2.y;
-                a.x += v3.x, a.y += v3.y;
-            }
-            for (; q < e; q++) {
-                const float2 v = *reinterpret_cast<const float2 *>(gt + srt[q] * LDS_RT + sub * 2);
-                a.x += v.x, a.y += v.y;
+            const float *gb = gt + sub * 2;
+            for (uint32_t q = s; q < e; q += 8) {
+                int id[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) id[i] = (q + i < e) ? (int)srt[q + i] : FT_CHUNK;  // pad -> zero row
+                float2 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = *reinterpret_cast<const float2 *>(gb + id[i] * LDS_RT);
+#pragma unroll
+                for (int i = 0; i < 8; i++) a.x += v[i].x, a.y += v[i].y;
             }
             float2 *dst = reinterpret_cast<float2 *>(acc + f * LDS_RT + sub * 2);  // owned by this group only
             float2 cur = *dst;
@@ -598,6 +655,7 @@ int ft_validate(const bt_ft_desc *d, const char *who) {
     BT_REQUIRE(d->rows + d->offset <= d->stride, "%s: %d + %d > %d", who, d->rows, d->offset, d->stride);  // sparse.rs:30-32
     BT_REQUIRE(d->n_inputs >= 1 && d->n_inputs <= 2, "%s: n_inputs must be 1 or 2", who);
     BT_REQUIRE(d->nnz <= 64, "%s: nnz > 64 unsupported", who);
+    BT_REQUIRE((long long)d->n_inputs * d->batch < (1ll << 30), "%s: batch too large", who);
     BT_REQUIRE(d->act >= BT_ACT_IDENTITY && d->act <= BT_ACT_SQRRELU, "%s: unknown activation", who);
     BT_REQUIRE(!d->pairwise || d->rows % 2 == 0, "%s: pairwise needs even rows", who);
     const int out_w = d->pairwise ? d->rows / 2 : d->rows;
@@ -633,7 +691,7 @@ int ft_plan(const bt_ft_desc *d, FtPlan *p) {
     o += bt_align((size_t)p->bias_blocks * d->rows * sizeof(float));
     // LDS-resident path: 32-row tiles, table tile + staging must fit the 160 KiB LDS
     p->lds_fwd_bytes = (size_t)(d->cols + 1) * LDS_RT * sizeof(float);
-    p->lds_bwd_bytes = ((size_t)d->cols * LDS_RT + FT_CHUNK * LDS_RT) * sizeof(float) +
+    p->lds_bwd_bytes = ((size_t)d->cols * LDS_RT + (FT_CHUNK + 1) * LDS_RT) * sizeof(float) +
                        (size_t)((d->cols + 2) & ~1) * sizeof(uint32_t) + (size_t)FT_CHUNK * d->nnz * sizeof(uint16_t);
     p->lds_path = (p->vec == 4) && (d->rows % LDS_RT == 0) && p->lds_bwd_bytes <= 160 * 1024 &&
                   p->lds_fwd_bytes <= 160 * 1024 && (d->nnz % 2 == 0 || true);

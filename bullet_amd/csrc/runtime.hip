@@ -33,7 +33,7 @@ struct Profiler {
 thread_local Profiler g_prof;
 const char *const kKernelNames[BTK_COUNT] = {
     "ft_fwd_generic", "ft_fwd_lds", "ft_index_kernel", "ft_bwd_make_g", "ft_bwd_gather", "ft_bwd_lds",
-    "ft_bwd_merge", "colsum_partial", "colsum_final", "dense_fwd_kernel", "dense_bwd_dx_kernel",
+    "ft_bwd_merge", "colsum_partial", "colsum_final", "dense_fwd_kernel", "dense_fwd_small", "dense_bwd_small", "dense_bwd_dx_kernel",
     "dense_bwd_dw_kernel", "sum_partials_kernel", "sigmoid_mse_kernel", "adamw_kernel"};
 }  // namespace
 
