@@ -24,6 +24,9 @@ namespace {
 
 constexpr int FT_CHUNK = 256;  // positions per index chunk (local ids fit u16)
 
+// entries of one chunk's sorted list: every pair plus <= 3 padding ids per feature (runs are 4-aligned)
+__host__ __device__ inline int ft_sorted_cap(int nnz, int cols) { return (FT_CHUNK * nnz + 3 * cols + 7) & ~7; }
+
 // tests: BT_FT_FORCE_GENERIC=1 runs the any-shape kernels on every shape
 bool force_generic() {
     const char *e = getenv("BT_FT_FORCE_GENERIC");
@@ -146,7 +149,7 @@ __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t 
     const int b0 = cb * FT_CHUNK;
     const int n_e = min(FT_CHUNK, batch - b0);
     const int32_t *idx = (k == 0 ? idx0 : idx1) + (size_t)b0 * nnz;
-    uint16_t *my_sorted = sorted + (size_t)c * FT_CHUNK * nnz;
+    uint16_t *my_sorted = sorted + (size_t)c * ft_sorted_cap(nnz, cols);
     uint32_t *my_offs = offs + (size_t)c * (cols + 1);
 
     for (int i = threadIdx.x; i < nwaves * cols; i += blockDim.x) cnt[i] = 0;
@@ -181,8 +184,11 @@ __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t 
         const int per = (cols + blockDim.x - 1) / blockDim.x;
         const int f_lo = min(cols, (int)threadIdx.x * per), f_hi = min(cols, f_lo + per);
         uint32_t s = 0;
-        for (int f = f_lo; f < f_hi; f++)
-            for (int w2 = 0; w2 < nwaves; w2++) s += cnt[(size_t)w2 * cols + f];
+        for (int f = f_lo; f < f_hi; f++) {
+            uint32_t t = 0;
+            for (int w2 = 0; w2 < nwaves; w2++) t += cnt[(size_t)w2 * cols + f];
+            s += (t + 3) & ~3u;  // every feature's run is padded to a multiple of 4 entries
+        }
         tsum[threadIdx.x] = s;
         __syncthreads();
         if (threadIdx.x == 0) {  // <= 256 values
@@ -192,7 +198,6 @@ __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t 
                 tsum[i] = run;
                 run += v;
             }
-            my_offs[cols] = run;
         }
         __syncthreads();
         uint32_t run = tsum[threadIdx.x];
@@ -203,7 +208,9 @@ __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t 
                 cnt[(size_t)w2 * cols + f] = run;
                 run += v;
             }
+            while (run & 3) my_sorted[run++] = (uint16_t)FT_CHUNK;  // pad the run; id FT_CHUNK = "add nothing"
         }
+        if (f_hi == cols && f_lo < cols) my_offs[cols] = run;
     }
     __syncthreads();
 
@@ -290,8 +297,9 @@ __global__ void ft_bwd_gather(const float *__restrict__ g, const uint16_t *__res
             if (s == e) continue;
             const int k = c / chunks_per_input, cb = c % chunks_per_input;
             const size_t ebase = (size_t)k * d.batch + (size_t)cb * FT_CHUNK;
-            const uint16_t *lst = sorted + (size_t)c * FT_CHUNK * d.nnz;
+            const uint16_t *lst = sorted + (size_t)c * ft_sorted_cap(d.nnz, d.cols);
             for (uint32_t q2 = s; q2 < e; q2++) {
+                if (lst[q2] >= FT_CHUNK) break;  // run padding
                 Vec<VEC> x = vload<VEC>(g + (ebase + lst[q2]) * d.rows + r0);
 #pragma unroll
                 for (int q = 0; q < VEC; q++) acc.v[q] += x.v[q];
@@ -346,20 +354,22 @@ __device__ __forceinline__ int tile_row(bool pair, int rt, int half_rows, int lo
 }
 
 // 8 gathers issued back to back (independent LDS reads in flight), then 8 ordered adds.
+// `reg` holds byte offsets f * 128 of this lane's index slots; row_share<n>(reg) + lane_off is a single
+// v_add_u32 with a DPP source operand, so one gather costs 2 VALU (address, packed add) + 1 ds_read_b64.
 template <int N0>
-__device__ __forceinline__ void fwd_block8(const float *wl, int reg, int sub, float2 &acc) {
-    const int f0 = row_share<N0 + 0>(reg), f1 = row_share<N0 + 1>(reg), f2 = row_share<N0 + 2>(reg),
-              f3 = row_share<N0 + 3>(reg), f4 = row_share<N0 + 4>(reg), f5 = row_share<N0 + 5>(reg),
-              f6 = row_share<N0 + 6>(reg), f7 = row_share<N0 + 7>(reg);
-    const float *base = wl + sub * 2;
-    const float2 v0 = *reinterpret_cast<const float2 *>(base + f0 * LDS_RT);
-    const float2 v1 = *reinterpret_cast<const float2 *>(base + f1 * LDS_RT);
-    const float2 v2 = *reinterpret_cast<const float2 *>(base + f2 * LDS_RT);
-    const float2 v3 = *reinterpret_cast<const float2 *>(base + f3 * LDS_RT);
-    const float2 v4 = *reinterpret_cast<const float2 *>(base + f4 * LDS_RT);
-    const float2 v5 = *reinterpret_cast<const float2 *>(base + f5 * LDS_RT);
-    const float2 v6 = *reinterpret_cast<const float2 *>(base + f6 * LDS_RT);
-    const float2 v7 = *reinterpret_cast<const float2 *>(base + f7 * LDS_RT);
+__device__ __forceinline__ void fwd_block8(const char *wl, int reg, int lane_off, float2 &acc) {
+    const int a0 = row_share<N0 + 0>(reg) + lane_off, a1 = row_share<N0 + 1>(reg) + lane_off,
+              a2 = row_share<N0 + 2>(reg) + lane_off, a3 = row_share<N0 + 3>(reg) + lane_off,
+              a4 = row_share<N0 + 4>(reg) + lane_off, a5 = row_share<N0 + 5>(reg) + lane_off,
+              a6 = row_share<N0 + 6>(reg) + lane_off, a7 = row_share<N0 + 7>(reg) + lane_off;
+    const float2 v0 = *reinterpret_cast<const float2 *>(wl + a0);
+    const float2 v1 = *reinterpret_cast<const float2 *>(wl + a1);
+    const float2 v2 = *reinterpret_cast<const float2 *>(wl + a2);
+    const float2 v3 = *reinterpret_cast<const float2 *>(wl + a3);
+    const float2 v4 = *reinterpret_cast<const float2 *>(wl + a4);
+    const float2 v5 = *reinterpret_cast<const float2 *>(wl + a5);
+    const float2 v6 = *reinterpret_cast<const float2 *>(wl + a6);
+    const float2 v7 = *reinterpret_cast<const float2 *>(wl + a7);
     acc.x += v0.x, acc.y += v0.y;
     acc.x += v1.x, acc.y += v1.y;
     acc.x += v2.x, acc.y += v2.y;
@@ -401,17 +411,15 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
     const int out_w = PAIR ? half_rows : d.rows;
 
     // raw index registers of the NEXT iteration are loaded while the current one is being summed
+    // Unconditional, clamped loads (validity is applied at decode time): with no branch around them the
+    // compiler keeps them in flight behind a counted s_waitcnt instead of draining with vmcnt(0).
     auto load_idx = [&](int eb2, int(&r)[NREG]) {
-        const int e2 = eb2 + eslot;
-        const bool lv = e2 < e_end;
-        const int k2 = (lv && e2 >= d.batch) ? 1 : 0;
-        const int b2 = lv ? e2 - k2 * d.batch : 0;
+        const int e2 = min(eb2 + eslot, E - 1);
+        const int k2 = (e2 >= d.batch) ? 1 : 0;
+        const int b2 = e2 - k2 * d.batch;
         const int32_t *ip = (k2 == 0 ? idx0 : idx1) + (size_t)b2 * d.nnz;
 #pragma unroll
-        for (int q = 0; q < NREG; q++) {
-            const int p = q * 16 + sub;
-            r[q] = (lv && p < d.nnz) ? ip[p] : -1;
-        }
+        for (int q = 0; q < NREG; q++) r[q] = ip[min(q * 16 + sub, d.nnz - 1)];
     };
     int nxt[NREG];
     load_idx(e_begin + wave * 4, nxt);
@@ -429,22 +437,21 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
         for (int q = NREG - 1; q >= 0; q--) {
             const int p = q * 16 + sub;
             const int j = reg[q];
-            const bool inval = (p >= d.nnz) || j < 0 || j >= d.cols;
+            const bool inval = !live || (p >= d.nnz) || j < 0 || j >= d.cols;
             const unsigned m = (unsigned)((__ballot(inval) >> (eslot * 16)) & 0xFFFFull);
             if (m) nvalid = q * 16 + __ffs((int)m) - 1;  // descending q: the smallest position wins
         }
-        if (!live) nvalid = 0;
 #pragma unroll
-        for (int q = 0; q < NREG; q++)
-            if (q * 16 + sub >= nvalid) reg[q] = d.cols;  // stop rule (write.rs:231): masked slots read the zero row
+        for (int q = 0; q < NREG; q++)  // stop rule (write.rs:231): masked slots read the zero row
+            reg[q] = ((q * 16 + sub >= nvalid) ? d.cols : reg[q]) * (LDS_RT * 4);
         const int maxcnt = max(max(__builtin_amdgcn_readlane(nvalid, 0), __builtin_amdgcn_readlane(nvalid, 16)),
                                max(__builtin_amdgcn_readlane(nvalid, 32), __builtin_amdgcn_readlane(nvalid, 48)));
         float2 acc = make_float2(0.0f, 0.0f);
 #pragma unroll
         for (int q = 0; q < NREG; q++) {
             // wave-uniform skips at 8-slot granularity; masked slots inside a block read the zero row
-            if (q * 16 < maxcnt) fwd_block8<0>(wl, reg[q], sub, acc);
-            if (q * 16 + 8 < maxcnt) fwd_block8<8>(wl, reg[q], sub, acc);
+            if (q * 16 < maxcnt) fwd_block8<0>(reinterpret_cast<const char *>(wl), reg[q], sub * 8, acc);
+            if (q * 16 + 8 < maxcnt) fwd_block8<8>(reinterpret_cast<const char *>(wl), reg[q], sub * 8, acc);
         }
         float2 c = make_float2(bt_act_fwd(d.act, acc.x + bv.x), bt_act_fwd(d.act, acc.y + bv.y));
         if constexpr (PAIR) {
@@ -493,8 +500,9 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
     // and consumed after it, so HBM latency overlaps the reduction without a second LDS buffer.
     constexpr int NPASS = FT_CHUNK / 128;
     float4 r_go[NPASS], r_a[NPASS], r_b[NPASS];
-    uint32_t r_srt[8], r_off[2];
-    const int srt_words = FT_CHUNK * d.nnz / 2;  // <= 8 * LDS_THREADS (nnz <= 64)
+    uint32_t r_srt[10], r_off[2];
+    const int srt_cap = ft_sorted_cap(d.nnz, d.cols);
+    const int srt_words = srt_cap / 2;  // <= 10 * LDS_THREADS (host-checked)
     auto prefetch = [&](int c) {
         const int k = c / chunks_per_input, cb = c % chunks_per_input;
         const int b0 = cb * FT_CHUNK;
@@ -524,9 +532,9 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
             const int q = threadIdx.x + i * LDS_THREADS;
             r_off[i] = (q <= d.cols) ? go_[q] : 0u;
         }
-        const uint32_t *gs = reinterpret_cast<const uint32_t *>(sorted + (size_t)c * FT_CHUNK * d.nnz);
+        const uint32_t *gs = reinterpret_cast<const uint32_t *>(sorted + (size_t)c * srt_cap);
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < 10; i++) {
             const int q = threadIdx.x + i * LDS_THREADS;
             r_srt[i] = (q < srt_words) ? gs[q] : 0u;
         }
@@ -568,7 +576,7 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
         {
             uint32_t *ls = reinterpret_cast<uint32_t *>(srt);
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < 10; i++) {
                 const int q = threadIdx.x + i * LDS_THREADS;
                 if (q < srt_words) ls[q] = r_srt[i];
             }
@@ -579,16 +587,18 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
             const uint32_t s = offl[f], e = offl[f + 1];
             if (s == e) continue;
             float2 a = make_float2(0.0f, 0.0f);
-            const float *gb = gt + sub * 2;
-            for (uint32_t q = s; q < e; q += 8) {
-                int id[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) id[i] = (q + i < e) ? (int)srt[q + i] : FT_CHUNK;  // pad -> zero row
-                float2 v[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) v[i] = *reinterpret_cast<const float2 *>(gb + id[i] * LDS_RT);
-#pragma unroll
-                for (int i = 0; i < 8; i++) a.x += v[i].x, a.y += v[i].y;
+            const char *gb = reinterpret_cast<const char *>(gt) + sub * 8;
+            // runs are padded to multiples of 4 with the zero-row id: no per-element predicates
+            for (uint32_t q = s; q < e; q += 4) {
+                const int i0 = srt[q], i1 = srt[q + 1], i2 = srt[q + 2], i3 = srt[q + 3];
+                const float2 v0 = *reinterpret_cast<const float2 *>(gb + i0 * (LDS_RT * 4));
+                const float2 v1 = *reinterpret_cast<const float2 *>(gb + i1 * (LDS_RT * 4));
+                const float2 v2 = *reinterpret_cast<const float2 *>(gb + i2 * (LDS_RT * 4));
+                const float2 v3 = *reinterpret_cast<const float2 *>(gb + i3 * (LDS_RT * 4));
+                a.x += v0.x, a.y += v0.y;
+                a.x += v1.x, a.y += v1.y;
+                a.x += v2.x, a.y += v2.y;
+                a.x += v3.x, a.y += v3.y;
             }
             float2 *dst = reinterpret_cast<float2 *>(acc + f * LDS_RT + sub * 2);  // owned by this group only
             float2 cur = *dst;
@@ -681,7 +691,7 @@ int ft_plan(const bt_ft_desc *d, FtPlan *p) {
     while ((1 << p->fbits) < d->cols) p->fbits++;
     size_t o = 0;
     p->off_sorted = o;
-    o += bt_align((size_t)p->nchunks * FT_CHUNK * d->nnz * sizeof(uint16_t));
+    o += bt_align((size_t)p->nchunks * ft_sorted_cap(d->nnz, d->cols) * sizeof(uint16_t));
     p->off_offs = o;
     o += bt_align((size_t)p->nchunks * (d->cols + 1) * sizeof(uint32_t));
     p->off_g = o;
@@ -692,9 +702,9 @@ int ft_plan(const bt_ft_desc *d, FtPlan *p) {
     // LDS-resident path: 32-row tiles, table tile + staging must fit the 160 KiB LDS
     p->lds_fwd_bytes = (size_t)(d->cols + 1) * LDS_RT * sizeof(float);
     p->lds_bwd_bytes = ((size_t)d->cols * LDS_RT + (FT_CHUNK + 1) * LDS_RT) * sizeof(float) +
-                       (size_t)((d->cols + 2) & ~1) * sizeof(uint32_t) + (size_t)FT_CHUNK * d->nnz * sizeof(uint16_t);
+                       (size_t)((d->cols + 2) & ~1) * sizeof(uint32_t) + (size_t)ft_sorted_cap(d->nnz, d->cols) * sizeof(uint16_t);
     p->lds_path = (p->vec == 4) && (d->rows % LDS_RT == 0) && p->lds_bwd_bytes <= 160 * 1024 &&
-                  p->lds_fwd_bytes <= 160 * 1024 && (d->nnz % 2 == 0 || true);
+                  p->lds_fwd_bytes <= 160 * 1024 && ft_sorted_cap(d->nnz, d->cols) / 2 <= 10 * LDS_THREADS;
     p->ntiles = d->rows / LDS_RT;
     p->G = 1, p->chunks_per_wg = p->nchunks;
     if (p->lds_path) {
@@ -789,12 +799,38 @@ size_t bt_ft_backward_workspace_bytes(const bt_ft_desc *d) {
     return p.total;
 }
 
+int bt_ft_build_index(void *stream, const bt_ft_desc *d, const int32_t *const *idx, void *workspace,
+                      size_t workspace_bytes) {
+    if (int rc = ft_validate(d, "bt_ft_build_index")) return rc;
+    BT_REQUIRE(idx && idx[0] && workspace, "bt_ft_build_index: null pointer");
+    BT_REQUIRE(d->n_inputs == 1 || idx[1], "bt_ft_build_index: null index pointer for input 1");
+    FtPlan p;
+    if (int rc = ft_plan(d, &p)) return rc;
+    BT_REQUIRE(workspace_bytes >= p.total, "bt_ft_build_index: workspace too small (%zu < %zu)", workspace_bytes, p.total);
+    hipStream_t s = bt_stream(stream);
+    char *ws = static_cast<char *>(workspace);
+    uint16_t *sorted = reinterpret_cast<uint16_t *>(ws + p.off_sorted);
+    uint32_t *offs = reinterpret_cast<uint32_t *>(ws + p.off_offs);
+    const int32_t *i0 = idx[0], *i1 = d->n_inputs > 1 ? idx[1] : idx[0];
+    const int threads = p.index_waves * 64;
+    const size_t lds = ((size_t)p.index_waves * d->cols + threads) * sizeof(uint32_t);
+    BT_LAUNCH(BTK_FT_INDEX, s, ft_index_kernel, dim3(p.nchunks), dim3(threads), lds, i0, i1, d->batch, d->nnz, d->cols,
+              p.chunks_per_input, p.fbits, sorted, offs);
+    BT_LAUNCH_CHECK();
+    return BT_OK;
+}
+
 int bt_ft_backward(void *stream, const bt_ft_desc *d, const int32_t *const *idx, const float *grad_out,
                    const float *out, const float *saved, float *dw, float *dbias, void *workspace,
                    size_t workspace_bytes) {
+    if (int rc = bt_ft_build_index(stream, d, idx, workspace, workspace_bytes)) return rc;
+    return bt_ft_backward_prebuilt(stream, d, grad_out, out, saved, dw, dbias, workspace, workspace_bytes);
+}
+
+int bt_ft_backward_prebuilt(void *stream, const bt_ft_desc *d, const float *grad_out, const float *out,
+                            const float *saved, float *dw, float *dbias, void *workspace, size_t workspace_bytes) {
     if (int rc = ft_validate(d, "bt_ft_backward")) return rc;
-    BT_REQUIRE(idx && idx[0] && grad_out && dw && workspace, "bt_ft_backward: null pointer");
-    BT_REQUIRE(d->n_inputs == 1 || idx[1], "bt_ft_backward: null index pointer for input 1");
+    BT_REQUIRE(grad_out && dw && workspace, "bt_ft_backward: null pointer");
     BT_REQUIRE(d->pairwise ? (saved != nullptr) : (out != nullptr), "bt_ft_backward: missing forward activations");
     FtPlan p;
     if (int rc = ft_plan(d, &p)) return rc;
@@ -805,15 +841,7 @@ int bt_ft_backward(void *stream, const bt_ft_desc *d, const int32_t *const *idx,
     uint32_t *offs = reinterpret_cast<uint32_t *>(ws + p.off_offs);
     float *g = reinterpret_cast<float *>(ws + p.off_g);
     float *bpart = reinterpret_cast<float *>(ws + p.off_bpart);
-    const int32_t *i0 = idx[0], *i1 = d->n_inputs > 1 ? idx[1] : idx[0];
 
-    {
-        const int threads = p.index_waves * 64;
-        const size_t lds = ((size_t)p.index_waves * d->cols + threads) * sizeof(uint32_t);
-        BT_LAUNCH(BTK_FT_INDEX, s, ft_index_kernel, dim3(p.nchunks), dim3(threads), lds, i0, i1, d->batch, d->nnz, d->cols,
-                           p.chunks_per_input, p.fbits, sorted, offs);
-        BT_LAUNCH_CHECK();
-    }
     if (p.lds_path && !force_generic()) {
         float *pw = reinterpret_cast<float *>(ws + p.off_pw), *pb = reinterpret_cast<float *>(ws + p.off_pb);
         dim3 grid(p.ntiles * p.G), block(LDS_THREADS);

@@ -21,6 +21,9 @@ struct bt_net {
     float *hid = nullptr, *saved = nullptr, *g_hid = nullptr, *grad_y = nullptr;
     float *a[BT_MAX_DENSE] = {nullptr}, *ga[BT_MAX_DENSE] = {nullptr};
     void *ft_ws = nullptr, *dense_ws = nullptr;
+    // side stream: the FT sorted index (depends only on the batch indices) is built while the forward runs
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_index = nullptr;
     size_t ft_ws_bytes = 0, dense_ws_bytes = 0;
 };
 
@@ -177,6 +180,12 @@ int bt_net_create(const bt_net_desc *desc, int max_batch, float *ext_params, flo
     if (n->ft_ws_bytes == 0) return fail(BT_ERR_INVALID);
     if ((rc = bt_malloc(&n->ft_ws, n->ft_ws_bytes))) return fail(rc);
     if ((rc = bt_malloc(&n->dense_ws, n->dense_ws_bytes))) return fail(rc);
+    if (hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&n->ev_index, hipEventDisableTiming) != hipSuccess) {
+        bt_set_error("bt_net_create: could not create the side stream / events");
+        return fail(BT_ERR_HIP);
+    }
     *out = n;
     return BT_OK;
 }
@@ -188,6 +197,9 @@ int bt_net_destroy(bt_net *n) {
     bt_free(n->mom), bt_free(n->vel), bt_free(n->hid), bt_free(n->g_hid), bt_free(n->saved), bt_free(n->grad_y);
     for (int k = 0; k < BT_MAX_DENSE; k++) bt_free(n->a[k]), bt_free(n->ga[k]);
     bt_free(n->ft_ws), bt_free(n->dense_ws);
+    if (n->ev_fork) (void)hipEventDestroy(n->ev_fork);
+    if (n->ev_index) (void)hipEventDestroy(n->ev_index);
+    if (n->side) (void)hipStreamDestroy(n->side);
     delete n;
     return BT_OK;
 }
@@ -221,6 +233,13 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
     if (int rc = check_batch(n, b, "bt_net_forward_backward")) return rc;
     BT_REQUIRE(loss_sum_dev, "bt_net_forward_backward: null loss buffer");
     hipStream_t s = bt_stream(stream);
+    bt_ft_desc f = ft_desc(n, b->batch);
+    const int32_t *idx[2] = {b->stm, b->nstm};
+    // fork: index build on the side stream, ordered after everything already queued on `s`
+    BT_HIP(hipEventRecord(n->ev_fork, s));
+    BT_HIP(hipStreamWaitEvent(n->side, n->ev_fork, 0));
+    if (int rc = bt_ft_build_index(n->side, &f, idx, n->ft_ws, n->ft_ws_bytes)) return rc;
+    BT_HIP(hipEventRecord(n->ev_index, n->side));
     if (int rc = forward_impl(n, s, b)) return rc;
     const int L = n->d.n_dense;
     if (int rc = bt_sigmoid_mse(s, b->batch, n->a[L - 1], b->targets,
@@ -236,10 +255,9 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
                                        n->dense_ws_bytes))
             return rc;
     }
-    bt_ft_desc f = ft_desc(n, b->batch);
-    const int32_t *idx[2] = {b->stm, b->nstm};
-    return bt_ft_backward(s, &f, idx, n->g_hid, n->hid, n->saved, n->grads + n->t_off[0], n->grads + n->t_off[1],
-                          n->ft_ws, n->ft_ws_bytes);
+    BT_HIP(hipStreamWaitEvent(s, n->ev_index, 0));  // join
+    return bt_ft_backward_prebuilt(s, &f, n->g_hid, n->hid, n->saved, n->grads + n->t_off[0], n->grads + n->t_off[1],
+                                   n->ft_ws, n->ft_ws_bytes);
 }
 
 int bt_net_optimiser_step(bt_net *n, void *stream, const float *adj_dev, const float *lr_dev) {

@@ -60,7 +60,8 @@ SYMBOLS = [
     "bt_host_alloc_pinned", "bt_host_free_pinned", "bt_stream_create", "bt_stream_destroy", "bt_stream_sync",
     "bt_memset_async", "bt_memcpy_h2d_async", "bt_memcpy_d2h_async", "bt_memcpy_d2d_async",
     "bt_profile_start", "bt_profile_stop", "bt_profile_num_kernels", "bt_profile_kernel_name",
-    "bt_ft_forward", "bt_ft_backward_workspace_bytes", "bt_ft_backward",
+    "bt_ft_forward", "bt_ft_backward_workspace_bytes", "bt_ft_backward", "bt_ft_build_index",
+    "bt_ft_backward_prebuilt",
     "bt_dense_forward", "bt_dense_backward_workspace_bytes", "bt_dense_backward",
     "bt_sigmoid_mse", "bt_adamw",
     "bt_net_param_count", "bt_net_num_tensors", "bt_net_tensor_size", "bt_net_tensor_offset", "bt_net_create",

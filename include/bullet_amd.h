@@ -130,6 +130,14 @@ int bt_ft_backward(void *stream, const bt_ft_desc *desc, const int32_t *const *i
                    const float *out, const float *saved, float *dw, float *dbias, void *workspace,
                    size_t workspace_bytes);
 
+/* The two halves of bt_ft_backward, for callers that overlap them: the sorted index depends only on
+ * `idx`, so it can be built on another stream while the forward pass runs (the reference keeps two
+ * streams too, run.rs:156-157). bt_ft_backward == bt_ft_build_index + bt_ft_backward_prebuilt. */
+int bt_ft_build_index(void *stream, const bt_ft_desc *desc, const int32_t *const *idx, void *workspace,
+                      size_t workspace_bytes);
+int bt_ft_backward_prebuilt(void *stream, const bt_ft_desc *desc, const float *grad_out, const float *out,
+                            const float *saved, float *dw, float *dbias, void *workspace, size_t workspace_bytes);
+
 /* Dense affine layer with optional output-bucket select and activation:
  * Matmul (linear/matmul.rs:62-93, lowered model/operations/linear.rs:128-149, device
  * function.rs:256-274 -> hipblasSgemm) + bias broadcast + Select (index/select.rs:12-26) + activation.
