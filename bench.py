@@ -175,14 +175,22 @@ def main():
             dist.all_reduce(net.loss)
         net.optimiser_step(adj, lr, stream)
 
+    # Per-kernel HIP-event timing costs ~20 % of a 0.4 ms step when every kernel is bracketed, so the full
+    # per-kernel table is taken over the warm-up steps and the timed region brackets only the dominant kernel.
+    profile = not args.no_profile
+    if profile and args.warmup > 0:
+        lib.profile_start(args.warmup * 16 + 64)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    warm = lib.profile_stop() if (profile and args.warmup > 0) else {}
+    # side-stream kernels overlap the main stream and never gate the step
+    cand = {k: v for k, v in warm.items() if k != "ft_index_kernel"}
+    dom = max(cand, key=lambda k: cand[k][1]) if cand else None
     if dist is not None:
         dist.barrier()
-    profile = not args.no_profile
-    if profile:
-        lib.profile_start(args.steps * 16 + 64)
+    if profile and dom:
+        lib.profile_start(args.steps * 2 + 64, only=[dom])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -191,7 +199,7 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kern = lib.profile_stop() if profile else {}
+    kern = lib.profile_stop() if (profile and dom) else {}
     loss_per_pos = net.loss.item() / global_batch
     if dist is not None:
         tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
@@ -212,10 +220,9 @@ def main():
                        "parallelism": f"dp{world}"},
             "final_loss": loss_per_pos,
         }
+        if warm:
+            out["kernels_us_per_step_warmup"] = {k: round(1e3 * ms / args.warmup, 2) for k, (c, ms) in warm.items()}
         if kern:
-            per_kernel = {k: {"launches": c, "avg_us": 1e3 * ms / c} for k, (c, ms) in kern.items()}
-            out["kernels_us_per_step"] = {k: round(1e3 * ms / args.steps, 2) for k, (c, ms) in kern.items()}
-            dom = max(kern, key=lambda k: kern[k][1])
             c, ms = kern[dom]
             abytes = algorithmic_bytes(dom, B, nbar)
             launches_per_step = c / args.steps
@@ -230,7 +237,6 @@ def main():
                 out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                                    "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": per_launch}
-            out["kernel_detail"] = per_kernel
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(batches[0], B)
         print(json.dumps(out))

@@ -57,13 +57,13 @@ enum BtKernelId {
     BTK_ADAMW,
     BTK_COUNT
 };
-bool bt_prof_enabled();
+bool bt_prof_enabled(int id);
 void bt_prof_record(int id, hipStream_t s, bool begin);
 struct BtProfScope {
     int id;
     hipStream_t s;
     bool on;
-    BtProfScope(int id_, hipStream_t s_) : id(id_), s(s_), on(bt_prof_enabled()) {
+    BtProfScope(int id_, hipStream_t s_) : id(id_), s(s_), on(bt_prof_enabled(id_)) {
         if (on) bt_prof_record(id, s, true);
     }
     ~BtProfScope() {

@@ -29,6 +29,7 @@ struct Profiler {
     size_t used = 0;
     std::vector<ProfRec> recs;
     hipEvent_t pending = nullptr;
+    unsigned long long filter = ~0ull;  // bit i set = kernel id i is timed
 };
 thread_local Profiler g_prof;
 const char *const kKernelNames[BTK_COUNT] = {
@@ -37,7 +38,7 @@ const char *const kKernelNames[BTK_COUNT] = {
     "dense_bwd_dw_kernel", "sum_partials_kernel", "sigmoid_mse_kernel", "adamw_kernel"};
 }  // namespace
 
-bool bt_prof_enabled() { return g_prof.on; }
+bool bt_prof_enabled(int id) { return g_prof.on && ((g_prof.filter >> id) & 1ull); }
 
 void bt_prof_record(int id, hipStream_t s, bool begin) {
     Profiler &p = g_prof;
@@ -67,7 +68,13 @@ int bt_profile_start(int max_launches) {
     p.used = 0;
     p.recs.clear();
     p.pending = nullptr;
+    p.filter = ~0ull;
     p.on = true;
+    return BT_OK;
+}
+
+int bt_profile_set_filter(unsigned long long kernel_mask) {
+    g_prof.filter = kernel_mask;
     return BT_OK;
 }
 

@@ -59,7 +59,7 @@ SYMBOLS = [
     "bt_device_count", "bt_device_set", "bt_device_props", "bt_device_sync", "bt_malloc", "bt_free",
     "bt_host_alloc_pinned", "bt_host_free_pinned", "bt_stream_create", "bt_stream_destroy", "bt_stream_sync",
     "bt_memset_async", "bt_memcpy_h2d_async", "bt_memcpy_d2h_async", "bt_memcpy_d2d_async",
-    "bt_profile_start", "bt_profile_stop", "bt_profile_num_kernels", "bt_profile_kernel_name",
+    "bt_profile_start", "bt_profile_set_filter", "bt_profile_stop", "bt_profile_num_kernels", "bt_profile_kernel_name",
     "bt_ft_forward", "bt_ft_backward_workspace_bytes", "bt_ft_backward", "bt_ft_build_index",
     "bt_ft_backward_prebuilt",
     "bt_dense_forward", "bt_dense_backward_workspace_bytes", "bt_dense_backward",
@@ -84,6 +84,7 @@ def load():
     L = C.CDLL(SO_PATH)
     L.bt_last_error.restype = C.c_char_p
     L.bt_profile_kernel_name.restype = C.c_char_p
+    L.bt_profile_set_filter.argtypes = [C.c_ulonglong]
     L.bt_profile_stop.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int]
     for f in ("bt_ft_backward_workspace_bytes", "bt_dense_backward_workspace_bytes", "bt_net_param_count",
               "bt_net_tensor_size", "bt_net_tensor_offset"):
@@ -132,8 +133,16 @@ def check(rc):
         raise BtError(f"[{rc}] {load().bt_last_error().decode()}")
 
 
-def profile_start(max_launches=100000):
-    check(load().bt_profile_start(max_launches))
+def profile_start(max_launches=100000, only=None):
+    """only: iterable of kernel names to time (None = all)"""
+    L = load()
+    check(L.bt_profile_start(max_launches))
+    if only is not None:
+        names = {L.bt_profile_kernel_name(i).decode(): i for i in range(L.bt_profile_num_kernels())}
+        mask = 0
+        for n in only:
+            mask |= 1 << names[n]
+        check(L.bt_profile_set_filter(mask))
 
 
 def profile_stop():

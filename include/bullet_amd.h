@@ -81,6 +81,8 @@ int bt_memcpy_d2d_async(void *dst, const void *src, size_t bytes, void *stream);
  * calling thread's profiler for up to max_launches kernel launches; bt_profile_stop waits for the
  * events and fills counts[id] / total_ms[id] for id < bt_profile_num_kernels(). */
 int bt_profile_start(int max_launches);
+/* restrict timing to the kernels whose id bit is set (after bt_profile_start); default all */
+int bt_profile_set_filter(unsigned long long kernel_mask);
 int bt_profile_stop(int *counts, double *total_ms, int n_ids);
 int bt_profile_num_kernels(void);
 const char *bt_profile_kernel_name(int id);
