@@ -123,11 +123,9 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from bullet_amd import lib
+    from bullet_amd import lib, parallel
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local_rank = parallel.env_world()
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
@@ -164,15 +162,13 @@ def main():
     for stm, ntm, bk, tg, w in batches:
         t = [torch.from_numpy(a).cuda() for a in (stm, ntm, bk, tg, w)]
         dev_batches.append(net.make_batch(*t))
-    adj = torch.tensor([1.0 / global_batch], device="cuda")
+    adj = torch.tensor([parallel.adj_factor(global_batch)], device="cuda")
     lr = torch.tensor([1e-3], device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(i):
         net.forward_backward(dev_batches[i % n_distinct], stream)
-        if dist is not None:
-            dist.all_reduce(net.grads)  # sum over ranks; replicas stay identical
-            dist.all_reduce(net.loss)
+        parallel.allreduce_step_buffers(dist, net.grads, net.loss)  # sum over ranks; replicas stay identical
         net.optimiser_step(adj, lr, stream)
 
     # Per-kernel HIP-event timing costs ~20 % of a 0.4 ms step when every kernel is bracketed, so the full
