@@ -1,0 +1,535 @@
+// Host side of the training loop: weight init, LR / WDL schedules, the looping fixed-size record reader and
+// run::train for one device.  Mirrors crates/trainer/src/{run.rs,reader.rs,reader/fixed_size.rs,
+// model/weights.rs} and crates/bullet_lib/src/trainer/schedule/{lr,wdl}.rs.
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------ weight init
+namespace {
+
+// rand_xoshiro 0.8.1: Xoroshiro128Plus, seed_from_u64 = two SplitMix64 outputs
+struct Xoroshiro128Plus {
+    uint64_t s0, s1;
+    explicit Xoroshiro128Plus(uint64_t seed) {
+        auto sm = [&seed]() {
+            seed += 0x9E3779B97F4A7C15ull;
+            uint64_t z = seed;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            return z ^ (z >> 31);
+        };
+        s0 = sm();
+        s1 = sm();
+    }
+    uint64_t next() {
+        const uint64_t a = s0;
+        uint64_t b = s1;
+        const uint64_t r = a + b;
+        b ^= a;
+        s0 = ((a << 24) | (a >> 40)) ^ b ^ (b << 16);
+        s1 = (b << 37) | (b >> 27);
+        return r;
+    }
+};
+
+// rand_distr 0.6.0 StandardNormal: 256-layer ziggurat (tables per its ziggurat_tables.py recipe)
+struct Ziggurat {
+    static constexpr double R = 3.654152885361008796;
+    double x[257], f[257];
+    Ziggurat() {
+        const double v = 0.00492867323399;
+        x[0] = v / std::exp(-R * R / 2.0);
+        x[1] = R;
+        for (int i = 2; i < 256; i++) x[i] = std::sqrt(-2.0 * std::log(v / x[i - 1] + std::exp(-x[i - 1] * x[i - 1] / 2.0)));
+        x[256] = 0.0;
+        for (int i = 0; i < 257; i++) f[i] = std::exp(-x[i] * x[i] / 2.0);
+    }
+    static double from_bits(uint64_t mant, int e) {
+        const uint64_t b = ((uint64_t)(1023 + e) << 52) | mant;
+        double d;
+        std::memcpy(&d, &b, 8);
+        return d;
+    }
+    double sample(Xoroshiro128Plus &rng) const {
+        const double eps_half = 2.220446049250313e-16 / 2.0;
+        for (;;) {
+            const uint64_t bits = rng.next();
+            const int i = (int)(bits & 0xff);
+            const double u = from_bits(bits >> 12, 1) - (3.0 - eps_half);
+            const double xv = u * x[i];
+            if (std::fabs(xv) < x[i + 1]) return xv;
+            if (i == 0) {
+                double a = 1.0, b = 0.0;
+                while (-2.0 * b < a * a) {
+                    const double ua = from_bits(rng.next() >> 12, 0) - (1.0 - eps_half);
+                    const double ub = from_bits(rng.next() >> 12, 0) - (1.0 - eps_half);
+                    a = std::log(ua) / R;
+                    b = std::log(ub);
+                }
+                return u < 0.0 ? a - R : R - a;
+            }
+            const double u01 = (double)(rng.next() >> 11) * (1.0 / 9007199254740992.0);
+            if (f[i + 1] + (f[i] - f[i + 1]) * u01 < std::exp(-xv * xv / 2.0)) return xv;
+        }
+    }
+};
+
+int dense_in_of(const bt_net_desc *d, int k) {
+    return k == 0 ? d->perspectives * (d->pairwise ? d->ft_out / 2 : d->ft_out) : d->dense_out[k - 1];
+}
+
+}  // namespace
+
+extern "C" int bt_net_init_weights_host(const bt_net_desc *d, uint64_t seed, int ft_eff, float *flat) {
+    BT_REQUIRE(d && flat, "bt_net_init_weights_host: null argument");
+    static const Ziggurat zig;
+    Xoroshiro128Plus rng(seed);
+    const int nt = bt_net_num_tensors(d);
+    std::memset(flat, 0, bt_net_param_count(d) * sizeof(float));
+    for (int t = 0; t < nt; t += 2) {  // even tensors = weights; biases (odd) stay zero and consume no RNG
+        const size_t n = bt_net_tensor_size(d, t);
+        float *dst = flat + bt_net_tensor_offset(d, t);
+        const int in = (t == 0) ? (ft_eff > 0 ? ft_eff : d->num_inputs) : dense_in_of(d, (t - 2) / 2);
+        const float stdev = std::sqrt(2.0f / ((float)in * 1.0f));
+        for (size_t i = 0; i < n; i++) dst[i] = 0.0f + stdev * (float)zig.sample(rng);
+    }
+    return BT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ schedules
+extern "C" float bt_lr_at(const bt_lr_sched *s, int batch, int superbatch) {
+    float lr = 0.0f;
+    switch (s->kind) {
+    case BT_LR_CONSTANT: lr = s->a; break;
+    case BT_LR_DROP: lr = superbatch > s->n ? s->a * s->b : s->a; break;
+    case BT_LR_STEP: {
+        const int steps = (superbatch > 0 ? superbatch - 1 : 0) / s->n;
+        lr = s->a * std::pow(s->b, (float)steps);  // powi
+    } break;
+    case BT_LR_LINEAR:
+        if (superbatch >= s->n) lr = s->b;
+        else {
+            const float lambda = (float)superbatch / (float)s->n;
+            lr = s->a + lambda * (s->b - s->a);
+        }
+        break;
+    case BT_LR_COSINE:
+        if (superbatch >= s->n) lr = s->b;
+        else {
+            const float progress = (float)superbatch / (float)s->n;
+            const float lambda = 1.0f - 0.5f * (1.0f + std::cos(3.14159265358979323846f * progress));
+            lr = s->a + lambda * (s->b - s->a);
+        }
+        break;
+    case BT_LR_EXP:
+        if (superbatch >= s->n) lr = s->b;
+        else {
+            const float lambda = (float)superbatch / (float)s->n;
+            lr = s->a * std::pow(s->b / s->a, lambda);
+        }
+        break;
+    }
+    if (s->warmup_batches > 0 && superbatch == 1 && batch < s->warmup_batches) lr = lr / (float)(s->warmup_batches - batch);
+    return lr;
+}
+
+extern "C" float bt_wdl_at(const bt_wdl_sched *s, int batch, int superbatch, int max) {
+    float w = s->start;
+    if (s->kind == BT_WDL_LINEAR) {
+        const int den = (max - 1) > 1 ? (max - 1) : 1;
+        const float grad = (s->end - s->start) / (float)den;
+        w = s->start + grad * (float)(superbatch - 1);
+    }
+    if (s->warmup_batches > 0 && superbatch == 1 && batch < s->warmup_batches) w = w / (float)(s->warmup_batches - batch);
+    return w;
+}
+
+// ------------------------------------------------------------------------------------------ reader
+struct bt_reader {
+    std::vector<std::string> paths;  // already rotated so that paths[0] is the start file
+    size_t file_idx = 0;
+    FILE *fp = nullptr;
+    uint64_t to_skip = 0;
+};
+
+namespace {
+bool file_records(const std::string &p, uint64_t *n) {
+    FILE *f = std::fopen(p.c_str(), "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END);
+    const long sz = std::ftell(f);
+    std::fclose(f);
+    *n = (uint64_t)sz / 32;
+    return true;
+}
+}  // namespace
+
+extern "C" int bt_reader_open(const char *const *paths, int n_paths, uint64_t start, bt_reader **out) {
+    BT_REQUIRE(paths && n_paths > 0 && out, "bt_reader_open: bad arguments");
+    std::vector<std::string> ps;
+    std::vector<uint64_t> counts;
+    uint64_t epoch = 0;
+    for (int i = 0; i < n_paths; i++) {
+        uint64_t n = 0;
+        if (!file_records(paths[i], &n)) {
+            bt_set_error("File not found: %s", paths[i]);  // fixed_size.rs:28
+            return BT_ERR_IO;
+        }
+        ps.push_back(paths[i]);
+        counts.push_back(n);
+        epoch += n;
+    }
+    if (epoch == 0) {
+        bt_set_error("bt_reader_open: no records in the given files");
+        return BT_ERR_IO;
+    }
+    start %= epoch;  // fixed_size.rs:48
+    size_t first = 0;
+    uint64_t before = 0;
+    for (size_t i = 0; i < ps.size(); i++) {  // fixed_size.rs:50-64
+        if (start < before + counts[i]) {
+            first = i;
+            break;
+        }
+        before += counts[i];
+    }
+    bt_reader *r = new bt_reader();
+    for (size_t i = 0; i < ps.size(); i++) r->paths.push_back(ps[(first + i) % ps.size()]);  // rotate_left
+    r->to_skip = start - before;
+    *out = r;
+    return BT_OK;
+}
+
+extern "C" int bt_reader_next(bt_reader *r, void *dst, int count) {
+    BT_REQUIRE(r && dst && count >= 0, "bt_reader_next: bad arguments");
+    uint8_t *p = static_cast<uint8_t *>(dst);
+    size_t need = (size_t)count;
+    int empty_opens = 0;
+    while (need > 0) {
+        if (!r->fp) {
+            r->fp = std::fopen(r->paths[r->file_idx].c_str(), "rb");
+            if (!r->fp) {
+                bt_set_error("File not found: %s", r->paths[r->file_idx].c_str());
+                return BT_ERR_IO;
+            }
+            if (r->to_skip > 0) {  // fixed_size.rs:80-84: only the first file opened is seeked
+                std::fseek(r->fp, (long)(r->to_skip * 32), SEEK_CUR);
+                r->to_skip = 0;
+            }
+        }
+        const size_t got = std::fread(p, 32, need, r->fp);
+        p += got * 32;
+        need -= got;
+        if (need > 0) {  // end of this file: next file, wrapping forever (fixed_size.rs:73-106)
+            std::fclose(r->fp);
+            r->fp = nullptr;
+            r->file_idx = (r->file_idx + 1) % r->paths.size();
+            empty_opens = got == 0 ? empty_opens + 1 : 0;
+            if (empty_opens > (int)r->paths.size() + 1) {
+                bt_set_error("bt_reader_next: data files became empty");
+                return BT_ERR_IO;
+            }
+        }
+    }
+    return BT_OK;
+}
+
+extern "C" int bt_reader_close(bt_reader *r) {
+    if (!r) return BT_OK;
+    if (r->fp) std::fclose(r->fp);
+    delete r;
+    return BT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ training loop
+namespace {
+
+struct HostSlot {  // one prepared batch in pinned memory (PreparedBatchHost)
+    int32_t *stm = nullptr, *nstm = nullptr, *buckets = nullptr;
+    float *targets = nullptr, *weights = nullptr;
+    int superbatch = 0, batch = 0;
+};
+
+struct DevSet {
+    int32_t *stm = nullptr, *nstm = nullptr, *buckets = nullptr;
+    float *targets = nullptr, *weights = nullptr;
+};
+
+struct Loader {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<int> ready, free_slots;
+    bool stop = false, failed = false;
+    std::string error;
+};
+
+int pinned(void **p, size_t bytes) { return bt_host_alloc_pinned(p, bytes); }
+
+}  // namespace
+
+extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_train_config *cfg,
+                            const char *const *paths, int n_paths, bt_batch_callback on_batch,
+                            bt_superbatch_callback on_superbatch, void *user) {
+    BT_REQUIRE(net && input && cfg && paths, "bt_train_run: null argument");
+    BT_REQUIRE(cfg->batch_size > 0 && cfg->batches_per_superbatch > 0 && cfg->start_superbatch >= 1 &&
+                   cfg->end_superbatch >= cfg->start_superbatch,
+               "bt_train_run: invalid TrainingSteps");
+    const int B = cfg->batch_size, nnz = bt_input_max_active(input);
+    const int bps = cfg->batches_per_superbatch;
+    const long long total_steps = (long long)(cfg->end_superbatch - cfg->start_superbatch + 1) * bps;
+
+    // reader.rs:40: skip batch_size * total_batches(start) records (resume)
+    bt_reader *reader = nullptr;
+    const uint64_t start_pos = (uint64_t)B * (uint64_t)bps * (uint64_t)(cfg->start_superbatch - 1);
+    if (int rc = bt_reader_open(paths, n_paths, start_pos, &reader)) return rc;
+
+    constexpr int RING = 4;
+    HostSlot slots[RING];
+    DevSet dev[2];
+    void *copy_stream = nullptr, *compute_stream = nullptr;
+    hipEvent_t uploaded[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr}, slot_copied[RING] = {nullptr};
+    constexpr int LOSS_RING = 4;
+    hipEvent_t loss_ready[LOSS_RING] = {nullptr};
+    float *loss_host = nullptr, *lr_host = nullptr, *loss_dev = nullptr, *lr_dev = nullptr, *adj_dev = nullptr;
+    std::vector<uint8_t> records((size_t)B * 32);
+    int rc = BT_OK;
+    Loader L;
+    std::thread loader_thread;
+
+    auto cleanup = [&]() {
+        {
+            std::lock_guard<std::mutex> g(L.mu);
+            L.stop = true;
+        }
+        L.cv.notify_all();
+        if (loader_thread.joinable()) loader_thread.join();
+        (void)hipDeviceSynchronize();
+        for (auto &s : slots) {
+            bt_host_free_pinned(s.stm), bt_host_free_pinned(s.nstm), bt_host_free_pinned(s.buckets);
+            bt_host_free_pinned(s.targets), bt_host_free_pinned(s.weights);
+        }
+        for (auto &d : dev) bt_free(d.stm), bt_free(d.nstm), bt_free(d.buckets), bt_free(d.targets), bt_free(d.weights);
+        for (auto e : uploaded) if (e) (void)hipEventDestroy(e);
+        for (auto e : consumed) if (e) (void)hipEventDestroy(e);
+        for (auto e : slot_copied) if (e) (void)hipEventDestroy(e);
+        for (auto e : loss_ready) if (e) (void)hipEventDestroy(e);
+        bt_host_free_pinned(loss_host), bt_host_free_pinned(lr_host);
+        bt_free(loss_dev), bt_free(lr_dev), bt_free(adj_dev);
+        bt_stream_destroy(copy_stream), bt_stream_destroy(compute_stream);
+        bt_reader_close(reader);
+    };
+#define TRY(x)                \
+    do {                      \
+        if ((rc = (x))) {     \
+            cleanup();        \
+            return rc;        \
+        }                     \
+    } while (0)
+#define TRY_HIP(x)                                                                   \
+    do {                                                                             \
+        hipError_t e_ = (x);                                                         \
+        if (e_ != hipSuccess) {                                                      \
+            bt_set_error("%s: %s", hipGetErrorName(e_), hipGetErrorString(e_));      \
+            cleanup();                                                               \
+            return BT_ERR_HIP;                                                       \
+        }                                                                            \
+    } while (0)
+
+    for (auto &s : slots) {
+        TRY(pinned((void **)&s.stm, sizeof(int32_t) * (size_t)B * nnz));
+        TRY(pinned((void **)&s.nstm, sizeof(int32_t) * (size_t)B * nnz));
+        TRY(pinned((void **)&s.buckets, sizeof(int32_t) * (size_t)B));
+        TRY(pinned((void **)&s.targets, sizeof(float) * (size_t)B));
+        TRY(pinned((void **)&s.weights, sizeof(float) * (size_t)B));
+        std::memset(s.stm, 0, sizeof(int32_t) * (size_t)B * nnz);
+        std::memset(s.nstm, 0, sizeof(int32_t) * (size_t)B * nnz);
+    }
+    for (auto &d : dev) {
+        TRY(bt_malloc((void **)&d.stm, sizeof(int32_t) * (size_t)B * nnz));
+        TRY(bt_malloc((void **)&d.nstm, sizeof(int32_t) * (size_t)B * nnz));
+        TRY(bt_malloc((void **)&d.buckets, sizeof(int32_t) * (size_t)B));
+        TRY(bt_malloc((void **)&d.targets, sizeof(float) * (size_t)B));
+        TRY(bt_malloc((void **)&d.weights, sizeof(float) * (size_t)B));
+    }
+    TRY(bt_stream_create(&copy_stream));
+    TRY(bt_stream_create(&compute_stream));
+    for (auto &e : uploaded) TRY_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : consumed) TRY_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : slot_copied) TRY_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : loss_ready) TRY_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    TRY(pinned((void **)&loss_host, sizeof(float) * LOSS_RING));
+    TRY(pinned((void **)&lr_host, sizeof(float) * LOSS_RING));
+    TRY(bt_malloc((void **)&loss_dev, sizeof(float) * LOSS_RING));
+    TRY(bt_malloc((void **)&lr_dev, sizeof(float) * LOSS_RING));
+    TRY(bt_malloc((void **)&adj_dev, sizeof(float)));
+    {
+        const float adj = 1.0f / (float)B;  // run.rs:130
+        TRY(bt_memcpy_h2d_async(adj_dev, &adj, sizeof(float), compute_stream));
+        TRY(bt_stream_sync(compute_stream));
+    }
+
+    // ---- loader thread (run.rs:94-103): reader -> mapper -> queue of prepared batches
+    for (int i = 0; i < RING; i++) L.free_slots.push_back(i);
+    loader_thread = std::thread([&]() {
+        int sb = cfg->start_superbatch, batch = 0;
+        for (long long step = 0; step < total_steps; step++) {
+            int slot;
+            {
+                std::unique_lock<std::mutex> g(L.mu);
+                L.cv.wait(g, [&] { return L.stop || !L.free_slots.empty(); });
+                if (L.stop) return;
+                slot = L.free_slots.front();
+                L.free_slots.pop_front();
+            }
+            bt_map_opts o;
+            o.out_buckets = cfg->out_buckets;
+            o.blend = bt_wdl_at(&cfg->wdl, batch, sb, cfg->end_superbatch);
+            o.eval_scale = cfg->eval_scale;
+            o.use_win_rate_model = cfg->use_win_rate_model;
+            o.wdl_output = 0;
+            o.threads = cfg->threads;
+            HostSlot &s = slots[slot];
+            int lrc = bt_reader_next(reader, records.data(), B);
+            if (!lrc) lrc = bt_map_batch(input, &o, records.data(), B, s.stm, s.nstm, s.buckets, s.targets, s.weights);
+            s.superbatch = sb, s.batch = batch;
+            {
+                std::lock_guard<std::mutex> g(L.mu);
+                if (lrc) {
+                    L.failed = true;
+                    L.error = bt_last_error();
+                } else {
+                    L.ready.push_back(slot);
+                }
+            }
+            L.cv.notify_all();
+            if (lrc) return;
+            if (++batch == bps) batch = 0, sb++;  // Step::step, run/schedule.rs:70-77
+        }
+    });
+
+    auto take_ready = [&](int *slot) -> int {
+        std::unique_lock<std::mutex> g(L.mu);
+        L.cv.wait(g, [&] { return L.failed || !L.ready.empty(); });
+        if (L.failed) {
+            bt_set_error("data loading failed: %s", L.error.c_str());
+            return BT_ERR_IO;
+        }
+        *slot = L.ready.front();
+        L.ready.pop_front();
+        return BT_OK;
+    };
+    auto upload = [&](int slot, int set) -> int {  // PreparedBatchHost::copy_to_device_async, dataloader.rs:41-54
+        HostSlot &s = slots[slot];
+        DevSet &d = dev[set];
+        if (int r2 = bt_memcpy_h2d_async(d.stm, s.stm, sizeof(int32_t) * (size_t)B * nnz, copy_stream)) return r2;
+        if (int r2 = bt_memcpy_h2d_async(d.nstm, s.nstm, sizeof(int32_t) * (size_t)B * nnz, copy_stream)) return r2;
+        if (int r2 = bt_memcpy_h2d_async(d.buckets, s.buckets, sizeof(int32_t) * (size_t)B, copy_stream)) return r2;
+        if (int r2 = bt_memcpy_h2d_async(d.targets, s.targets, sizeof(float) * (size_t)B, copy_stream)) return r2;
+        if (int r2 = bt_memcpy_h2d_async(d.weights, s.weights, sizeof(float) * (size_t)B, copy_stream)) return r2;
+        BT_HIP(hipEventRecord(slot_copied[slot], bt_stream(copy_stream)));
+        BT_HIP(hipEventRecord(uploaded[set], bt_stream(copy_stream)));
+        return BT_OK;
+    };
+    auto release_slot = [&](int slot) -> int {
+        BT_HIP(hipEventSynchronize(slot_copied[slot]));
+        {
+            std::lock_guard<std::mutex> g(L.mu);
+            L.free_slots.push_back(slot);
+        }
+        L.cv.notify_all();
+        return BT_OK;
+    };
+
+    using clock = std::chrono::steady_clock;
+    const auto t_start = clock::now();
+    auto sb_timer = clock::now();
+    auto secs = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<float>(b - a).count(); };
+
+    int cur_slot = -1, prev_slot = -1;
+    TRY(take_ready(&cur_slot));
+    TRY(upload(cur_slot, 0));
+    int sb = cfg->start_superbatch, batch = 0;
+    float running_loss = 0.0f;
+    long long sb_positions = 0;
+    struct Pending {
+        int sb, batch;
+    };
+    std::deque<Pending> pending;  // losses in flight, delivered in order
+    auto deliver = [&](bool flush) -> int {
+        while (!pending.empty() && (flush || (int)pending.size() >= LOSS_RING - 1)) {
+            const Pending p = pending.front();
+            const long long k = (long long)(p.sb - cfg->start_superbatch) * bps + p.batch;
+            BT_HIP(hipEventSynchronize(loss_ready[k % LOSS_RING]));
+            const float error = loss_host[k % LOSS_RING] / (float)B;  // run.rs:221
+            pending.pop_front();
+            running_loss += error;
+            sb_positions += B;
+            if (on_batch) on_batch(user, p.sb, p.batch, error);
+            if (cfg->log_rate > 0 && p.batch % cfg->log_rate == 0 && p.batch > 0) {
+                const float t = secs(sb_timer, clock::now());
+                std::printf("superbatch %d [%.1f%% (%d/%d batches, %.0f pos/sec)]\n", p.sb, 100.0f * p.batch / bps, p.batch,
+                            bps, sb_positions / t);
+            }
+            if (p.batch == bps - 1) {  // run.rs:232-247
+                const float t = secs(sb_timer, clock::now());
+                const float err = running_loss / (float)bps;
+                if (cfg->log_rate > 0)
+                    std::printf("superbatch %d | time %.1fs | running loss %.6f | %.0f pos/sec | total time %.1fs\n", p.sb,
+                                t, err, sb_positions / t, secs(t_start, clock::now()));
+                if (on_superbatch) on_superbatch(user, p.sb, err, sb_positions / t);
+                running_loss = 0.0f, sb_positions = 0, sb_timer = clock::now();
+            }
+        }
+        return BT_OK;
+    };
+
+    for (long long step = 0; step < total_steps; step++) {
+        const int set = (int)(step & 1);
+        const int ring = (int)(step % LOSS_RING);
+        // compute waits for this batch's upload; the learning rate goes through a pinned ring (run.rs:171-173)
+        TRY_HIP(hipStreamWaitEvent(bt_stream(compute_stream), uploaded[set], 0));
+        lr_host[ring] = bt_lr_at(&cfg->lr, batch, sb);
+        TRY(bt_memcpy_h2d_async(lr_dev + ring, lr_host + ring, sizeof(float), compute_stream));
+        bt_batch bb;
+        bb.batch = B;
+        bb.stm = dev[set].stm, bb.nstm = dev[set].nstm, bb.buckets = dev[set].buckets;
+        bb.targets = dev[set].targets, bb.entry_weights = dev[set].weights;
+        TRY(bt_net_forward_backward(net, compute_stream, &bb, loss_dev + ring));
+        TRY(bt_net_optimiser_step(net, compute_stream, adj_dev, lr_dev + ring));
+        TRY_HIP(hipEventRecord(consumed[set], bt_stream(compute_stream)));
+        TRY(bt_memcpy_d2h_async(loss_host + ring, loss_dev + ring, sizeof(float), compute_stream));
+        TRY_HIP(hipEventRecord(loss_ready[ring], bt_stream(compute_stream)));
+        pending.push_back({sb, batch});
+
+        // next batch: upload into the other device set while this step computes (run.rs:194-207)
+        if (prev_slot >= 0) TRY(release_slot(prev_slot));
+        prev_slot = cur_slot;
+        if (step + 1 < total_steps) {
+            TRY(take_ready(&cur_slot));
+            if (step >= 1) TRY_HIP(hipStreamWaitEvent(bt_stream(copy_stream), consumed[set ^ 1], 0));
+            TRY(upload(cur_slot, set ^ 1));
+        }
+        TRY(deliver(false));
+        if (++batch == bps) batch = 0, sb++;
+    }
+    TRY(deliver(true));
+    TRY(bt_stream_sync(compute_stream));
+    if (cfg->log_rate > 0) {
+        const unsigned total = (unsigned)secs(t_start, clock::now());
+        std::printf("Total Training Time: %uh %um %us\n", total / 3600, (total / 60) % 60, total % 60);
+    }
+    cleanup();
+    return BT_OK;
+#undef TRY
+#undef TRY_HIP
+}

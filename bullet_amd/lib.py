@@ -48,6 +48,27 @@ class InputDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("factorised", C.c_int), ("buckets", C.c_int * 64), ("num_buckets", C.c_int)]
 
 
+class LrSched(C.Structure):
+    _fields_ = [("kind", C.c_int), ("a", C.c_float), ("b", C.c_float), ("n", C.c_int), ("warmup_batches", C.c_int)]
+
+
+class WdlSched(C.Structure):
+    _fields_ = [("kind", C.c_int), ("start", C.c_float), ("end", C.c_float), ("warmup_batches", C.c_int)]
+
+
+class TrainConfig(C.Structure):
+    _fields_ = [("batch_size", C.c_int), ("batches_per_superbatch", C.c_int), ("start_superbatch", C.c_int),
+                ("end_superbatch", C.c_int), ("lr", LrSched), ("wdl", WdlSched), ("eval_scale", C.c_float),
+                ("out_buckets", C.c_int), ("use_win_rate_model", C.c_int), ("threads", C.c_int),
+                ("log_rate", C.c_int)]
+
+
+BATCH_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_float)
+SUPERBATCH_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_float, C.c_float)
+LR = {"constant": 0, "drop": 1, "step": 2, "linear": 3, "cosine": 4, "exp": 5}
+WDL = {"constant": 0, "linear": 1}
+
+
 class MapOpts(C.Structure):
     _fields_ = [("out_buckets", C.c_int), ("blend", C.c_float), ("eval_scale", C.c_float),
                 ("use_win_rate_model", C.c_int), ("wdl_output", C.c_int), ("threads", C.c_int)]
@@ -68,6 +89,8 @@ SYMBOLS = [
     "bt_net_destroy", "bt_net_params", "bt_net_grads", "bt_net_momentum", "bt_net_velocity", "bt_net_set_adamw",
     "bt_net_forward_backward", "bt_net_optimiser_step", "bt_net_forward",
     "bt_input_init", "bt_input_num_inputs", "bt_input_max_active", "bt_map_batch",
+    "bt_net_init_weights_host", "bt_lr_at", "bt_wdl_at", "bt_reader_open", "bt_reader_next", "bt_reader_close",
+    "bt_train_run",
 ]
 
 _lib = None
@@ -124,6 +147,16 @@ def load():
     L.bt_input_num_inputs.argtypes = [C.POINTER(InputDesc)]
     L.bt_input_max_active.argtypes = [C.POINTER(InputDesc)]
     L.bt_map_batch.argtypes = [C.POINTER(InputDesc), C.POINTER(MapOpts), C.c_void_p, C.c_int] + [C.c_void_p] * 5
+    L.bt_net_init_weights_host.argtypes = [C.POINTER(NetDesc), C.c_uint64, C.c_int, C.c_void_p]
+    L.bt_lr_at.restype = C.c_float
+    L.bt_lr_at.argtypes = [C.POINTER(LrSched), C.c_int, C.c_int]
+    L.bt_wdl_at.restype = C.c_float
+    L.bt_wdl_at.argtypes = [C.POINTER(WdlSched), C.c_int, C.c_int, C.c_int]
+    L.bt_reader_open.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.bt_reader_next.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.bt_reader_close.argtypes = [C.c_void_p]
+    L.bt_train_run.argtypes = [C.c_void_p, C.POINTER(InputDesc), C.POINTER(TrainConfig), C.POINTER(C.c_char_p), C.c_int,
+                               BATCH_CB, SUPERBATCH_CB, C.c_void_p]
     _lib = L
     return L
 
@@ -222,6 +255,38 @@ class Net:
 
     def tensor(self, flat, t):
         return flat[self.offsets[t]:self.offsets[t] + self.sizes[t]]
+
+    def init_weights(self, seed=198273612, ft_effective_inputs=0):
+        """ModelWeights::new with the reference's RNG stream, uploaded to the device."""
+        import numpy as np
+        import torch
+        host = np.zeros(self.n_flat, dtype=np.float32)
+        check(self.L.bt_net_init_weights_host(C.byref(self.desc), seed, ft_effective_inputs, host.ctypes.data))
+        self.params.copy_(torch.from_numpy(host).to(self.params.device))
+
+    def train(self, input_desc, paths, batch_size, batches_per_superbatch, end_superbatch, lr, wdl, eval_scale=400.0,
+              start_superbatch=1, out_buckets=1, threads=4, log_rate=0, win_rate_model=False, on_batch=None,
+              on_superbatch=None):
+        """run::train through the C ABI. lr / wdl: LrSched / WdlSched. Returns [(superbatch, running_loss, pos/s)]."""
+        import torch
+        torch.cuda.synchronize()
+        cfg = TrainConfig(batch_size, batches_per_superbatch, start_superbatch, end_superbatch, lr, wdl, eval_scale,
+                          out_buckets, int(win_rate_model), threads, log_rate)
+        report = []
+
+        def sb_cb(_u, sb, loss, pps):
+            report.append((sb, loss, pps))
+            if on_superbatch:
+                on_superbatch(sb, loss, pps)
+
+        def b_cb(_u, sb, b, loss):
+            if on_batch:
+                on_batch(sb, b, loss)
+
+        cpaths = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+        check(self.L.bt_train_run(self.h, C.byref(input_desc), C.byref(cfg), cpaths, len(paths), BATCH_CB(b_cb),
+                                  SUPERBATCH_CB(sb_cb), None))
+        return report
 
     def set_params(self, arrays):
         import torch

@@ -275,6 +275,65 @@ typedef struct {
 int bt_map_batch(const bt_input_desc *d, const bt_map_opts *o, const void *records, int count, int32_t *stm,
                  int32_t *nstm, int32_t *buckets, float *targets, float *weights);
 
+/* ------------------------------------------------------------------------------------------
+ * 5. Weight init, schedules, data reader and the superbatch training loop
+ *    (crates/trainer/src/model/weights.rs:52-74, crates/bullet_lib/src/trainer/schedule/{lr,wdl}.rs,
+ *     crates/trainer/src/reader/fixed_size.rs, crates/trainer/src/reader.rs, crates/trainer/src/run.rs:75-265)
+ * ------------------------------------------------------------------------------------------ */
+
+/* ModelWeights::new(defn, seed) for a bt_net_desc net into a HOST flat buffer of bt_net_param_count()
+ * floats: one Xoroshiro128+ stream (seed_from_u64) consumed tensor by tensor in creation order, weights
+ * Normal(0, sqrt(2/inputs)), biases zero (crates/compiler/src/model/builder.rs:108-119).
+ * ft_effective_inputs > 0 = Affine::init_with_effective_input_size for l0 (builder.rs:149-152). */
+int bt_net_init_weights_host(const bt_net_desc *desc, uint64_t seed, int ft_effective_inputs, float *flat_host);
+
+/* LrScheduler (schedule/lr.rs): value of the learning rate for (batch, superbatch) */
+enum { BT_LR_CONSTANT = 0, BT_LR_DROP = 1, BT_LR_STEP = 2, BT_LR_LINEAR = 3, BT_LR_COSINE = 4, BT_LR_EXP = 5 };
+typedef struct {
+    int kind;           /* BT_LR_*                                                                    */
+    float a;            /* ConstantLR.value | DropLR/StepLR.start | Linear/Cosine/Exp .initial_lr     */
+    float b;            /* DropLR/StepLR.gamma | Linear/Cosine/Exp .final_lr                           */
+    int n;              /* DropLR.drop | StepLR.step | Linear/Cosine/Exp .final_superbatch             */
+    int warmup_batches; /* > 0 wraps the scheduler in Warmup{inner, warmup_batches} (lr.rs:168-191)    */
+} bt_lr_sched;
+float bt_lr_at(const bt_lr_sched *s, int batch, int superbatch);
+
+/* WdlScheduler (schedule/wdl.rs) */
+enum { BT_WDL_CONSTANT = 0, BT_WDL_LINEAR = 1 };
+typedef struct {
+    int kind;
+    float start, end;   /* ConstantWDL.value = start; LinearWDL.{start,end} */
+    int warmup_batches;
+} bt_wdl_sched;
+float bt_wdl_at(const bt_wdl_sched *s, int batch, int superbatch, int final_superbatch);
+
+/* FixedSizeDataReader / DirectSequentialDataLoader over 32-byte records: files are read in order and looped
+ * forever; start_position (records) is taken modulo the epoch size and may start in a later file
+ * (fixed_size.rs:42-107). bt_reader_next always delivers exactly `count` records (ReadMapLoader's
+ * re-chunking with carry-over, reader.rs:31-81). */
+typedef struct bt_reader bt_reader;
+int bt_reader_open(const char *const *paths, int n_paths, uint64_t start_position, bt_reader **reader);
+int bt_reader_next(bt_reader *reader, void *dst_records, int count);
+int bt_reader_close(bt_reader *reader);
+
+/* run::train (run.rs:75-265) for one device: loader thread (reader -> bt_map_batch into a pinned ring) ->
+ * double-buffered async H2D on a copy stream || fwd+bwd+AdamW on a compute stream; the loss of each batch is
+ * read back asynchronously and delivered in order (the reference syncs every batch, run.rs:209-221). */
+typedef struct {
+    int batch_size, batches_per_superbatch, start_superbatch, end_superbatch; /* TrainingSteps, run/schedule.rs:5-11 */
+    bt_lr_sched lr;
+    bt_wdl_sched wdl;
+    float eval_scale;        /* TrainingSchedule::eval_scale */
+    int out_buckets;         /* MaterialCount<N> */
+    int use_win_rate_model;
+    int threads;             /* LocalSettings::threads */
+    int log_rate;            /* progress line every log_rate batches (reference: 128); 0 = silent */
+} bt_train_config;
+typedef void (*bt_batch_callback)(void *user, int superbatch, int batch, float loss);
+typedef void (*bt_superbatch_callback)(void *user, int superbatch, float running_loss, float positions_per_sec);
+int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_train_config *cfg, const char *const *paths,
+                 int n_paths, bt_batch_callback on_batch, bt_superbatch_callback on_superbatch, void *user);
+
 #ifdef __cplusplus
 }
 #endif

@@ -175,3 +175,46 @@ def test_full_size_config2_properties():
     # ntm lists contain the same two kings with colours swapped -> already included above (shared W)
     torch.testing.assert_close(own, 2 * gb, rtol=2e-4, atol=1e-4 * float(gb.abs().max()))
     net.close()
+
+
+@pytest.mark.parametrize("hidden,expected", [(32, "0.056420"), (128, "0.044886")])
+def test_train_run_reproduces_reference_examples(hidden, expected):
+    """examples/tests/test1.rs / test3.rs end to end through bt_train_run: reader (looping batch.bf), threaded
+    mapper, pinned double-buffered upload, fwd/bwd/AdamW, weights from the reference RNG stream (product-side
+    bt_net_init_weights_host), ConstantLR 1e-3, ConstantWDL 0.2, 10 superbatches x 1 batch x 16384."""
+    cfg = dict(num_inputs=768, nnz=32, ft_out=hidden, ft_act="screlu", dense=[(1, "identity", False)])
+    net = lib.Net(lib.make_net_desc(**cfg), 16384)
+    net.init_weights()
+    per_batch = []
+    rep = net.train(lib.make_input_desc("chess768"), [GOLDEN], 16384, 1, 10,
+                    lib.LrSched(lib.LR["constant"], 0.001, 0, 0, 0), lib.WdlSched(lib.WDL["constant"], 0.2, 0, 0),
+                    threads=4, on_batch=lambda sb, b, l: per_batch.append((sb, b, l)))
+    assert [r[0] for r in rep] == list(range(1, 11)) and [p[:2] for p in per_batch] == [(i, 0) for i in range(1, 11)]
+    assert "%.6f" % rep[-1][1] == expected
+    net.close()
+
+
+def test_train_run_resume_matches_continuous_run(tmp_path):
+    """start_superbatch > 1 skips batch_size * batches done records (reader.rs:40) so that a resumed run sees
+    the same batches: 6 superbatches in one go == 3 + (weights carried over) 3."""
+    cfg = dict(num_inputs=768, nnz=32, ft_out=64, ft_act="screlu", num_buckets=8, dense=[(1, "identity", True)])
+    # ConstantWDL: LinearWDL's blend depends on the final superbatch, which differs between the segments
+    lr, wdl = lib.LrSched(lib.LR["step"], 0.002, 0.5, 2, 0), lib.WdlSched(lib.WDL["constant"], 0.3, 0, 0)
+    idesc = lib.make_input_desc("chess768")
+
+    def run(segments):
+        net = lib.Net(lib.make_net_desc(**cfg), 2048)
+        net.init_weights(seed=7)
+        losses = []
+        for s0, s1 in segments:
+            losses += net.train(idesc, [GOLDEN], 2048, 3, s1, lr, wdl, start_superbatch=s0, out_buckets=8)
+        w = net.params.clone()
+        net.close()
+        return losses, w
+
+    full, w_full = run([(1, 6)])
+    split, w_split = run([(1, 3), (4, 6)])
+    assert [r[0] for r in split] == [1, 2, 3, 4, 5, 6]
+    # AdamW moments live in the net, so the resumed run is the same computation: bit-identical
+    assert [r[1] for r in full] == [r[1] for r in split]
+    assert torch.equal(w_full, w_split)
