@@ -120,6 +120,10 @@ def main():
                     help="pieces per synthetic position: 32 (worst case) or the batch.bf histogram (mean 16.2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--live-loader", type=int, default=0, metavar="BATCHES",
+                    help="also time bt_train_run (file reader + threaded mapper + pinned H2D + step) over this many "
+                         "batches and report it as `live_loader` (not part of `value`)")
+    ap.add_argument("--loader-threads", type=int, default=16)
     args = ap.parse_args()
 
     import torch
@@ -233,6 +237,16 @@ def main():
                 out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                                    "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": per_launch}
+        if args.live_loader > 0 and world == 1:
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, "synthetic.bf")
+                synth_records(B * 8, 0xB011E7000 + 99, args.occupancy).tofile(path)
+                nb = args.live_loader
+                rep = net.train(idesc, [path], B, nb, 2, lib.LrSched(lib.LR["constant"], 1e-3, 0, 0, 0),
+                                lib.WdlSched(lib.WDL["constant"], 0.75, 0, 0), out_buckets=8, threads=args.loader_threads)
+                out["live_loader"] = {"positions_per_sec": rep[-1][2], "batches": nb, "threads": args.loader_threads,
+                                      "note": "second superbatch of bt_train_run: reader + mapper + H2D + step"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(batches[0], B)
         print(json.dumps(out))
