@@ -76,6 +76,25 @@ struct BtProfScope {
         hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);          \
     } while (0)
 
+// ---- internal cross-file entry points (not in the public header)
+bool bt_internal_ft_fused_ok(const bt_ft_desc *d, int head_rows);
+int bt_internal_ft_backward_fused(void *stream, const bt_ft_desc *d, const float *gz, const float *w1,
+                                  const int32_t *bucket, int head_rows, const float *out, const float *saved, float *dw,
+                                  float *dbias, void *workspace, size_t workspace_bytes);
+// dense head (out == 1) backward with optional extras: gz_out [B] receives grad_y * f'(y); when loss_partials is
+// given, block (0,0) also sums them in order into loss_sum[0]
+int bt_internal_dense_backward_head(void *stream, const bt_dense_desc *d, const float *w, const float *x,
+                                    const int32_t *bucket, const float *y, const float *grad_y, float *dw, float *dbias,
+                                    float *grad_x, float *gz_out, const float *loss_partials, int n_loss_partials,
+                                    float *loss_sum, void *workspace, size_t workspace_bytes);
+bool bt_internal_dense_head_ok(const bt_dense_desc *d);
+// dense head forward fused with sigmoid-MSE: writes y, grad_y and per-workgroup loss partials
+int bt_internal_dense_forward_loss(void *stream, const bt_dense_desc *d, const float *w, const float *bias,
+                                   const float *x, const int32_t *bucket, const float *targets,
+                                   const float *entry_weights, float *y, float *grad_y, float *loss_partials,
+                                   int *n_loss_partials);
+bool bt_internal_dense_forward_loss_ok(const bt_dense_desc *d);
+
 // ---- device-side activation helpers (semantics: dfo.rs:47-103, pointwise.rs:54-139) ----
 __device__ __forceinline__ float bt_act_fwd(int act, float v) {
     switch (act) {

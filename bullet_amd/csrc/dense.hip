@@ -215,13 +215,23 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamTable tab, const float *
 // loads (HBM-bound on x) and reads the selected bucket's rows from LDS.
 constexpr int DF_THREADS = 1024;
 
-template <int NX>
+// LOSS (final layer, out == 1): sigmoid + squared error + gradient are applied to y right where it is produced and
+// each workgroup emits one loss partial (positions in ascending order per wave, waves combined in order).
+struct LossArgs {
+    const float *targets, *entry_weights;
+    float *grad_y, *loss_partials;
+};
+
+template <int NX, bool LOSS>
 __global__ __launch_bounds__(DF_THREADS) void dense_fwd_small(const float *__restrict__ w,
                                                               const float *__restrict__ bias,
                                                               const float *__restrict__ x,
                                                               const int32_t *__restrict__ bucket,
-                                                              float *__restrict__ y, bt_dense_desc d, int pos_per_wg) {
+                                                              float *__restrict__ y, bt_dense_desc d, int pos_per_wg,
+                                                              LossArgs la) {
     extern __shared__ float wt[];  // [rows][in + 4]
+    __shared__ float wave_loss[DF_THREADS / 64];
+    float loss_acc = 0.0f;
     const int rows = d.out * d.buckets;
     const int ldw = d.in + 4;
     for (int q = threadIdx.x; q < rows * d.in; q += DF_THREADS) {
@@ -249,7 +259,27 @@ __global__ __launch_bounds__(DF_THREADS) void dense_fwd_small(const float *__res
                 acc += xv[j].w * w4.w;
             }
             const float sum = wave_sum(acc);
-            if (lane == 0) y[(size_t)b * d.out + o] = bt_act_fwd(d.act, sum + bias[base + o]);
+            const float yv = bt_act_fwd(d.act, sum + bias[base + o]);
+            if (lane == 0) y[(size_t)b * d.out + o] = yv;
+            if constexpr (LOSS) {  // same arithmetic as sigmoid_mse_kernel
+                const float sg = 1.0f / (1.0f + expf(-1.0f * yv));
+                const float diff = sg + (-1.0f * la.targets[b]);
+                const float g = la.entry_weights ? la.entry_weights[b] : 1.0f;
+                float l = diff * diff;
+                if (la.entry_weights) l = g * l;
+                loss_acc += l;
+                const float dd = g * diff + g * diff;
+                if (lane == 0) la.grad_y[b] = dd * (sg * (1.0f + (-1.0f * sg)));
+            }
+        }
+    }
+    if constexpr (LOSS) {
+        if (lane == 0) wave_loss[wave] = loss_acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.0f;
+            for (int i = 0; i < DF_THREADS / 64; i++) t += wave_loss[i];
+            la.loss_partials[blockIdx.x] = t;
         }
     }
 }
@@ -264,8 +294,16 @@ __global__ __launch_bounds__(256) void dense_bwd_small(const float *__restrict__
                                                        const float *__restrict__ y,
                                                        const float *__restrict__ grad_y,
                                                        float *__restrict__ part_w, float *__restrict__ part_b,
-                                                       float *__restrict__ grad_x, bt_dense_desc d, int range) {
+                                                       float *__restrict__ grad_x, bt_dense_desc d, int range,
+                                                       float *__restrict__ gz_out,
+                                                       const float *__restrict__ loss_partials, int n_loss_partials,
+                                                       float *__restrict__ loss_sum) {
     const int rows = d.buckets;  // out == 1
+    if (loss_partials && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        float t = 0.0f;  // fixed-order final sum of the forward kernel's loss partials
+        for (int i = 0; i < n_loss_partials; i++) t += loss_partials[i];
+        loss_sum[0] = t;
+    }
     const int in4 = d.in >> 2;
     const int c4 = blockIdx.x * 256 + threadIdx.x;
     const bool active = c4 < in4;
@@ -298,6 +336,7 @@ __global__ __launch_bounds__(256) void dense_bwd_small(const float *__restrict__
             accb[r] += m;
         }
         if (grad_x && active) gx4[(size_t)b * in4 + c4] = gx;
+        if (gz_out && blockIdx.x == 0 && threadIdx.x == 0) gz_out[b] = gz;
     }
     if (active) {
         float *pw = part_w + (size_t)blockIdx.y * rows * d.in + (size_t)rows * (c4 * 4);
@@ -312,7 +351,7 @@ __global__ __launch_bounds__(256) void dense_bwd_small(const float *__restrict__
     }
 }
 
-constexpr int DBS_RANGE = 64;  // positions per workgroup in dense_bwd_small
+constexpr int DBS_RANGE = 128;  // positions per workgroup in dense_bwd_small
 
 bool dense_fwd_small_ok(const bt_dense_desc *d) {
     const int rows = d->out * d->buckets;
@@ -327,6 +366,61 @@ int dense_set_lds(K kernel, size_t bytes) {
     return BT_OK;
 }
 
+int dense_fwd_small_launch(hipStream_t s, const bt_dense_desc *d, const float *w, const float *bias, const float *x,
+                           const int32_t *bucket, float *y, const LossArgs *la, int *n_partials) {
+    const int rows = d->out * d->buckets;
+    const size_t lds = (size_t)rows * (d->in + 4) * sizeof(float);
+    int nwg = bt_div_up(d->batch, 64);
+    if (nwg > 256) nwg = 256;
+    const int ppw = bt_div_up(d->batch, nwg);
+    nwg = bt_div_up(d->batch, ppw);
+    if (n_partials) *n_partials = nwg;
+    const LossArgs none{nullptr, nullptr, nullptr, nullptr};
+#define DFS(NX)                                                                                                   \
+    case NX:                                                                                                      \
+        if (la) {                                                                                                 \
+            if (int rc = dense_set_lds(dense_fwd_small<NX, true>, lds)) return rc;                                \
+            BT_LAUNCH(BTK_DENSE_FWD_SMALL, s, (dense_fwd_small<NX, true>), dim3(nwg), dim3(DF_THREADS), lds, w, bias, x, \
+                      bucket, y, *d, ppw, *la);                                                                   \
+        } else {                                                                                                  \
+            if (int rc = dense_set_lds(dense_fwd_small<NX, false>, lds)) return rc;                               \
+            BT_LAUNCH(BTK_DENSE_FWD_SMALL, s, (dense_fwd_small<NX, false>), dim3(nwg), dim3(DF_THREADS), lds, w, bias, x, \
+                      bucket, y, *d, ppw, none);                                                                  \
+        }                                                                                                         \
+        break;
+    switch (d->in / 256) {
+        DFS(1) DFS(2) DFS(3) DFS(4) DFS(5) DFS(6) DFS(7) DFS(8)
+    }
+#undef DFS
+    BT_LAUNCH_CHECK();
+    return BT_OK;
+}
+
+int dense_bwd_small_launch(hipStream_t s, const bt_dense_desc *d, const float *w, const float *x, const int32_t *bucket,
+                           const float *y, const float *grad_y, float *dw, float *dbias, float *grad_x, float *gz_out,
+                           const float *loss_partials, int n_loss_partials, float *loss_sum, float *part_w,
+                           float *part_b, int nr) {
+    const int rows = d->out * d->buckets;
+    dim3 grid(bt_div_up(d->in / 4, 256), nr), block(256);
+#define DBS(R)                                                                                                   \
+    BT_LAUNCH(BTK_DENSE_BWD_SMALL, s, (dense_bwd_small<R>), grid, block, 0, w, x, bucket, y, grad_y, part_w, part_b, \
+              grad_x, *d, DBS_RANGE, gz_out, loss_partials, n_loss_partials, loss_sum)
+    if (rows <= 1) DBS(1);
+    else if (rows <= 2) DBS(2);
+    else if (rows <= 4) DBS(4);
+    else if (rows <= 8) DBS(8);
+    else DBS(16);
+#undef DBS
+    BT_LAUNCH_CHECK();
+    const size_t nw = (size_t)rows * d->in;
+    BT_LAUNCH(BTK_SUM_PARTIALS, s, sum_partials_kernel, dim3(bt_div_up(nw, 32)), dim3(256), 0, part_w, nr, nw, dw);
+    BT_LAUNCH_CHECK();
+    BT_LAUNCH(BTK_SUM_PARTIALS, s, sum_partials_kernel, dim3(bt_div_up(rows, 32)), dim3(256), 0, part_b, nr,
+              (size_t)rows, dbias);
+    BT_LAUNCH_CHECK();
+    return BT_OK;
+}
+
 int dense_validate(const bt_dense_desc *d, const char *who) {
     BT_REQUIRE(d, "%s: null descriptor", who);
     BT_REQUIRE(d->batch > 0 && d->in > 0 && d->out > 0 && d->buckets > 0, "%s: Mismatched sizes! (non-positive dim)", who);
@@ -338,6 +432,41 @@ int dense_validate(const bt_dense_desc *d, const char *who) {
 
 }  // namespace
 
+// ---- internal entry points used by net.hip (declared in common.h)
+bool bt_internal_dense_head_ok(const bt_dense_desc *d) { return dense_validate(d, "dense_head_ok") == BT_OK && dense_bwd_small_ok(d); }
+
+int bt_internal_dense_backward_head(void *stream, const bt_dense_desc *d, const float *w, const float *x,
+                                    const int32_t *bucket, const float *y, const float *grad_y, float *dw, float *dbias,
+                                    float *grad_x, float *gz_out, const float *loss_partials, int n_loss_partials,
+                                    float *loss_sum, void *workspace, size_t workspace_bytes) {
+    if (int rc = dense_validate(d, "bt_dense_backward")) return rc;
+    BT_REQUIRE(dense_bwd_small_ok(d), "bt_dense_backward(head): shape not supported");
+    BT_REQUIRE(w && x && y && grad_y && dw && dbias && workspace, "bt_dense_backward: null pointer");
+    BT_REQUIRE(workspace_bytes >= bt_dense_backward_workspace_bytes(d), "bt_dense_backward: workspace too small");
+    const int rows = d->out * d->buckets;
+    const int nr = bt_div_up(d->batch, DBS_RANGE);
+    float *part_w = static_cast<float *>(workspace);
+    float *part_b = reinterpret_cast<float *>(static_cast<char *>(workspace) +
+                                              bt_align((size_t)nr * rows * d->in * sizeof(float)));
+    return dense_bwd_small_launch(bt_stream(stream), d, w, x, bucket, y, grad_y, dw, dbias, grad_x, gz_out, loss_partials,
+                                  n_loss_partials, loss_sum, part_w, part_b, nr);
+}
+
+bool bt_internal_dense_forward_loss_ok(const bt_dense_desc *d) {
+    return dense_validate(d, "dense_forward_loss_ok") == BT_OK && d->out == 1 && dense_fwd_small_ok(d);
+}
+
+int bt_internal_dense_forward_loss(void *stream, const bt_dense_desc *d, const float *w, const float *bias,
+                                   const float *x, const int32_t *bucket, const float *targets,
+                                   const float *entry_weights, float *y, float *grad_y, float *loss_partials,
+                                   int *n_loss_partials) {
+    if (int rc = dense_validate(d, "bt_dense_forward")) return rc;
+    BT_REQUIRE(bt_internal_dense_forward_loss_ok(d), "bt_dense_forward(loss): shape not supported");
+    BT_REQUIRE(w && bias && x && y && targets && grad_y && loss_partials, "bt_dense_forward(loss): null pointer");
+    const LossArgs la{targets, entry_weights, grad_y, loss_partials};
+    return dense_fwd_small_launch(bt_stream(stream), d, w, bias, x, bucket, y, &la, n_loss_partials);
+}
+
 extern "C" {
 
 int bt_dense_forward(void *stream, const bt_dense_desc *d, const float *w, const float *bias, const float *x,
@@ -345,27 +474,7 @@ int bt_dense_forward(void *stream, const bt_dense_desc *d, const float *w, const
     if (int rc = dense_validate(d, "bt_dense_forward")) return rc;
     BT_REQUIRE(w && bias && x && y, "bt_dense_forward: null pointer");
     BT_REQUIRE(d->buckets == 1 || bucket, "bt_dense_forward: bucketed layer needs bucket indices");
-    if (dense_fwd_small_ok(d)) {
-        hipStream_t s = bt_stream(stream);
-        const int rows = d->out * d->buckets;
-        const size_t lds = (size_t)rows * (d->in + 4) * sizeof(float);
-        int nwg = bt_div_up(d->batch, 64);
-        if (nwg > 256) nwg = 256;
-        const int ppw = bt_div_up(d->batch, nwg);
-        nwg = bt_div_up(d->batch, ppw);
-#define DFS(NX)                                                                                              \
-    case NX:                                                                                                 \
-        if (int rc = dense_set_lds(dense_fwd_small<NX>, lds)) return rc;                                     \
-        BT_LAUNCH(BTK_DENSE_FWD_SMALL, s, (dense_fwd_small<NX>), dim3(nwg), dim3(DF_THREADS), lds, w, bias, x, bucket, \
-                  y, *d, ppw);                                                                               \
-        break;
-        switch (d->in / 256) {
-            DFS(1) DFS(2) DFS(3) DFS(4) DFS(5) DFS(6) DFS(7) DFS(8)
-        }
-#undef DFS
-        BT_LAUNCH_CHECK();
-        return BT_OK;
-    }
+    if (dense_fwd_small_ok(d)) return dense_fwd_small_launch(bt_stream(stream), d, w, bias, x, bucket, y, nullptr, nullptr);
     BT_LAUNCH(BTK_DENSE_FWD, bt_stream(stream), dense_fwd_kernel, dim3(bt_div_up(d->batch, 4)), dim3(256), 0, w, bias, x,
                        bucket, y, *d);
     BT_LAUNCH_CHECK();
@@ -393,26 +502,9 @@ int bt_dense_backward(void *stream, const bt_dense_desc *d, const float *w, cons
     float *part_w = static_cast<float *>(workspace);
     float *part_b = reinterpret_cast<float *>(static_cast<char *>(workspace) +
                                               bt_align((size_t)nr * rows * d->in * sizeof(float)));
-    if (small) {
-        dim3 grid(bt_div_up(d->in / 4, 256), nr), block(256);
-#define DBS(R)                                                                                                   \
-    BT_LAUNCH(BTK_DENSE_BWD_SMALL, s, (dense_bwd_small<R>), grid, block, 0, w, x, bucket, y, grad_y, part_w, part_b, \
-              grad_x, *d, DBS_RANGE)
-        if (rows <= 1) DBS(1);
-        else if (rows <= 2) DBS(2);
-        else if (rows <= 4) DBS(4);
-        else if (rows <= 8) DBS(8);
-        else DBS(16);
-#undef DBS
-        BT_LAUNCH_CHECK();
-        const size_t nw = (size_t)rows * d->in;
-        BT_LAUNCH(BTK_SUM_PARTIALS, s, sum_partials_kernel, dim3(bt_div_up(nw, 32)), dim3(256), 0, part_w, nr, nw, dw);
-        BT_LAUNCH_CHECK();
-        BT_LAUNCH(BTK_SUM_PARTIALS, s, sum_partials_kernel, dim3(bt_div_up(rows, 32)), dim3(256), 0, part_b, nr,
-                  (size_t)rows, dbias);
-        BT_LAUNCH_CHECK();
-        return BT_OK;
-    }
+    if (small)
+        return dense_bwd_small_launch(s, d, w, x, bucket, y, grad_y, dw, dbias, grad_x, nullptr, nullptr, 0, nullptr, part_w,
+                                      part_b, nr);
     if (grad_x) {
         BT_LAUNCH(BTK_DENSE_BWD_DX, s, dense_bwd_dx_kernel, dim3(bt_div_up((long long)d->batch * d->in, 256)), dim3(256), 0, w,
                            bucket, y, grad_y, grad_x, *d);

@@ -470,8 +470,18 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
 }
 
 // backward: workgroup (row tile rt, chunk group cg) -> partial_w[cg][cols][stride], partial_b[cg][rows]
-template <bool PAIR>
-__global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restrict__ grad_out,
+// FUSED: the incoming gradient is not read from memory but formed on the fly from a one-output dense head,
+// grad_out[b][k*out_w + c] = gz[b] * W1[bucket[b]][k*out_w + c]  (Matmul::backward dX = W^T dY with a single
+// selected row, matmul.rs:117-123 + select.rs:93-110), so the [B][2H] gradient buffer never exists.
+struct FtFusedSrc {
+    const float *gz;        // [B] gradient w.r.t. the head's pre-activation
+    const float *w1;        // head weights, column-major [w1_rows][n_inputs*out_w]
+    const int32_t *bucket;  // [B] or null
+    int w1_rows;            // = number of output buckets (one output each)
+};
+
+template <bool PAIR, bool FUSED>
+__global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restrict__ grad_out, FtFusedSrc fs,
                                                           const float *__restrict__ out,
                                                           const float *__restrict__ saved,
                                                           const uint16_t *__restrict__ sorted,
@@ -483,12 +493,20 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
     float *acc = lds_f;                                   // [cols][32]
     float *gt = acc + (size_t)d.cols * LDS_RT;            // [FT_CHUNK + 1][32], last row = zeros (padding target)
     uint32_t *offl = reinterpret_cast<uint32_t *>(gt + (FT_CHUNK + 1) * LDS_RT);  // [cols + 1]
-    uint16_t *srt = reinterpret_cast<uint16_t *>(offl + ((d.cols + 1 + 1) & ~1));  // [FT_CHUNK * nnz]
+    uint16_t *srt = reinterpret_cast<uint16_t *>(offl + ((d.cols + 1 + 1) & ~1));  // [ft_sorted_cap]
+    float *w1t = reinterpret_cast<float *>(srt + ft_sorted_cap(d.nnz, d.cols));     // FUSED: [n_inputs][w1_rows][TW]
     const int rt = blockIdx.x % ntiles, cg = blockIdx.x / ntiles;
     const int half_rows = d.rows / 2;
     const int nchunks = d.n_inputs * chunks_per_input;
     const int out_w = PAIR ? half_rows : d.rows;
+    constexpr int TW = PAIR ? 16 : 32;  // output columns per perspective covered by this row tile
 
+    if constexpr (FUSED) {
+        for (int q = threadIdx.x; q < d.n_inputs * fs.w1_rows * TW; q += LDS_THREADS) {
+            const int c = q % TW, bk = (q / TW) % fs.w1_rows, k = q / (TW * fs.w1_rows);
+            w1t[q] = fs.w1[(size_t)(k * out_w + rt * TW + c) * fs.w1_rows + bk];
+        }
+    }
     for (int q = threadIdx.x; q < d.cols * LDS_RT; q += LDS_THREADS) acc[q] = 0.0f;
     if (threadIdx.x < LDS_RT) gt[FT_CHUNK * LDS_RT + threadIdx.x] = 0.0f;
 
@@ -513,15 +531,20 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
             r_go[pass] = r_a[pass] = r_b[pass] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (el < n_e) {
                 const int b = b0 + el;
+                if constexpr (FUSED) {
+                    r_go[pass].x = fs.gz[b];
+                    r_go[pass].y = __int_as_float(fs.bucket ? fs.bucket[b] : 0);
+                }
                 if constexpr (PAIR) {
                     const int col16 = rt * 16 + (s8 & 3) * 4;
-                    r_go[pass] = *reinterpret_cast<const float4 *>(grad_out + (size_t)b * d.out_ld + (size_t)k * out_w + col16);
+                    if constexpr (!FUSED)
+                        r_go[pass] = *reinterpret_cast<const float4 *>(grad_out + (size_t)b * d.out_ld + (size_t)k * out_w + col16);
                     const float *sv = saved + ((size_t)k * d.batch + b) * d.rows;
                     r_a[pass] = *reinterpret_cast<const float4 *>(sv + col16);
                     r_b[pass] = *reinterpret_cast<const float4 *>(sv + half_rows + col16);
                 } else {
                     const size_t o = (size_t)b * d.out_ld + (size_t)k * out_w + rt * LDS_RT + s8 * 4;
-                    r_go[pass] = *reinterpret_cast<const float4 *>(grad_out + o);
+                    if constexpr (!FUSED) r_go[pass] = *reinterpret_cast<const float4 *>(grad_out + o);
                     r_a[pass] = *reinterpret_cast<const float4 *>(out + o);
                 }
             }
@@ -542,13 +565,21 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
     if (c_lo < c_hi) prefetch(c_lo);
     for (int c = c_lo; c < c_hi; c++) {
         const int cb = c % chunks_per_input;
+        const int kc = c / chunks_per_input;
         const int n_e = min(FT_CHUNK, d.batch - cb * FT_CHUNK);
         __syncthreads();  // previous chunk's readers are done with gt / srt / offl
 #pragma unroll
         for (int pass = 0; pass < NPASS; pass++) {
             const int el = el0 + pass * 128;
             if (el < n_e) {
-                const float4 go = r_go[pass];
+                float4 go = r_go[pass];
+                if constexpr (FUSED) {
+                    const float gzv = go.x;
+                    const int bk = __float_as_int(go.y);
+                    const float4 wv = *reinterpret_cast<const float4 *>(
+                        w1t + (kc * fs.w1_rows + bk) * TW + (PAIR ? (s8 & 3) : s8) * 4);
+                    go = make_float4(gzv * wv.x, gzv * wv.y, gzv * wv.z, gzv * wv.w);
+                }
                 float4 g;
                 if constexpr (PAIR) {
                     const float4 c0 = r_a[pass], c1 = r_b[pass];
@@ -651,6 +682,7 @@ struct FtPlan {
     bool lds_path;
     int ntiles, G, chunks_per_wg;
     size_t lds_fwd_bytes, lds_bwd_bytes, off_pw, off_pb;
+    static constexpr int kFusedMaxRows = 16;  // head rows (buckets) the fused backward keeps in LDS
     int vec;
     int chunks_per_input, nchunks;
     int index_waves;
@@ -729,6 +761,61 @@ int set_lds(K kernel, size_t bytes) {
     return BT_OK;
 }
 
+int ft_backward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, const float *grad_out, FtFusedSrc fs,
+                           const float *out, const float *saved, const uint16_t *sorted, const uint32_t *offs, char *ws,
+                           float *dw, float *dbias) {
+    float *pw = reinterpret_cast<float *>(ws + p.off_pw), *pb = reinterpret_cast<float *>(ws + p.off_pb);
+    dim3 grid(p.ntiles * p.G), block(LDS_THREADS);
+    const bool fused = fs.gz != nullptr;
+    const size_t lds = p.lds_bwd_bytes + (fused ? (size_t)d->n_inputs * fs.w1_rows * 32 * sizeof(float) : 0);
+#define BWD_LDS(PAIR, FUSED)                                                                                        \
+    do {                                                                                                            \
+        if (int rc = set_lds(ft_bwd_lds<PAIR, FUSED>, lds)) return rc;                                              \
+        BT_LAUNCH(BTK_FT_BWD_LDS, s, (ft_bwd_lds<PAIR, FUSED>), grid, block, lds, grad_out, fs, out, saved, sorted, offs, \
+                  pw, pb, *d, p.ntiles, p.chunks_per_input, p.chunks_per_wg);                                       \
+    } while (0)
+    if (d->pairwise) {
+        if (fused) BWD_LDS(true, true);
+        else BWD_LDS(true, false);
+    } else {
+        if (fused) BWD_LDS(false, true);
+        else BWD_LDS(false, false);
+    }
+#undef BWD_LDS
+    BT_LAUNCH_CHECK();
+    if (d->rows != d->stride) BT_HIP(hipMemsetAsync(dw, 0, (size_t)d->stride * d->cols * sizeof(float), s));
+    const long long n = (long long)d->cols * (d->rows / 4) + d->rows;
+    BT_LAUNCH(BTK_FT_BWD_MERGE, s, ft_bwd_merge, dim3(bt_div_up(n, 256)), dim3(256), 0, pw, pb, dw, dbias, *d, p.G);
+    BT_LAUNCH_CHECK();
+    return BT_OK;
+}
+
+}  // namespace
+
+// ---- internal (not part of the public header): FT backward fed by a one-output dense head, used by net.hip
+bool bt_internal_ft_fused_ok(const bt_ft_desc *d, int head_rows) {
+    FtPlan p;
+    if (ft_validate(d, "ft_fused_ok") || ft_plan(d, &p)) return false;
+    return p.lds_path && !force_generic() && head_rows >= 1 && head_rows <= FtPlan::kFusedMaxRows &&
+           p.lds_bwd_bytes + (size_t)d->n_inputs * head_rows * 32 * sizeof(float) <= 160 * 1024;
+}
+
+int bt_internal_ft_backward_fused(void *stream, const bt_ft_desc *d, const float *gz, const float *w1,
+                                  const int32_t *bucket, int head_rows, const float *out, const float *saved, float *dw,
+                                  float *dbias, void *workspace, size_t workspace_bytes) {
+    if (int rc = ft_validate(d, "bt_ft_backward")) return rc;
+    BT_REQUIRE(gz && w1 && dw && workspace, "bt_ft_backward(fused): null pointer");
+    BT_REQUIRE(bt_internal_ft_fused_ok(d, head_rows), "bt_ft_backward(fused): shape not supported");
+    FtPlan p;
+    if (int rc = ft_plan(d, &p)) return rc;
+    BT_REQUIRE(workspace_bytes >= p.total, "bt_ft_backward: workspace too small (%zu < %zu)", workspace_bytes, p.total);
+    char *ws = static_cast<char *>(workspace);
+    return ft_backward_lds_launch(bt_stream(stream), d, p, nullptr, FtFusedSrc{gz, w1, bucket, head_rows}, out, saved,
+                                  reinterpret_cast<const uint16_t *>(ws + p.off_sorted),
+                                  reinterpret_cast<const uint32_t *>(ws + p.off_offs), ws, dw, dbias);
+}
+
+namespace {
 }  // namespace
 
 extern "C" {
@@ -842,25 +929,9 @@ int bt_ft_backward_prebuilt(void *stream, const bt_ft_desc *d, const float *grad
     float *g = reinterpret_cast<float *>(ws + p.off_g);
     float *bpart = reinterpret_cast<float *>(ws + p.off_bpart);
 
-    if (p.lds_path && !force_generic()) {
-        float *pw = reinterpret_cast<float *>(ws + p.off_pw), *pb = reinterpret_cast<float *>(ws + p.off_pb);
-        dim3 grid(p.ntiles * p.G), block(LDS_THREADS);
-        if (d->pairwise) {
-            if (int rc = set_lds(ft_bwd_lds<true>, p.lds_bwd_bytes)) return rc;
-            BT_LAUNCH(BTK_FT_BWD_LDS, s, (ft_bwd_lds<true>), grid, block, p.lds_bwd_bytes, grad_out, out, saved, sorted,
-                      offs, pw, pb, *d, p.ntiles, p.chunks_per_input, p.chunks_per_wg);
-        } else {
-            if (int rc = set_lds(ft_bwd_lds<false>, p.lds_bwd_bytes)) return rc;
-            BT_LAUNCH(BTK_FT_BWD_LDS, s, (ft_bwd_lds<false>), grid, block, p.lds_bwd_bytes, grad_out, out, saved, sorted,
-                      offs, pw, pb, *d, p.ntiles, p.chunks_per_input, p.chunks_per_wg);
-        }
-        BT_LAUNCH_CHECK();
-        if (d->rows != d->stride) BT_HIP(hipMemsetAsync(dw, 0, (size_t)d->stride * d->cols * sizeof(float), s));
-        const long long n = (long long)d->cols * (d->rows / 4) + d->rows;
-        BT_LAUNCH(BTK_FT_BWD_MERGE, s, ft_bwd_merge, dim3(bt_div_up(n, 256)), dim3(256), 0, pw, pb, dw, dbias, *d, p.G);
-        BT_LAUNCH_CHECK();
-        return BT_OK;
-    }
+    if (p.lds_path && !force_generic())
+        return ft_backward_lds_launch(s, d, p, grad_out, FtFusedSrc{nullptr, nullptr, nullptr, 0}, out, saved, sorted, offs,
+                                      ws, dw, dbias);
     {
         const int out_w = d->pairwise ? d->rows / 2 : d->rows;
         const long long total = (long long)d->n_inputs * d->batch * (out_w / p.vec);

@@ -19,6 +19,10 @@ struct bt_net {
     bt_adamw_tensor adam[BT_ADAMW_MAX_TENSORS];
     // activations
     float *hid = nullptr, *saved = nullptr, *g_hid = nullptr, *grad_y = nullptr;
+    float *gz0 = nullptr;            // [B] head pre-activation gradient (fused FT backward)
+    float *loss_partials = nullptr;  // per-workgroup loss partials of the fused head forward
+    int n_loss_partials = 0;
+    bool fuse_loss = false, fuse_ft = false;
     float *a[BT_MAX_DENSE] = {nullptr}, *ga[BT_MAX_DENSE] = {nullptr};
     void *ft_ws = nullptr, *dense_ws = nullptr;
     // side stream: the FT sorted index (depends only on the batch indices) is built while the forward runs
@@ -81,15 +85,22 @@ int check_batch(const bt_net *net, const bt_batch *b, const char *who) {
     return BT_OK;
 }
 
-int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b) {
+int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss) {
     bt_ft_desc f = ft_desc(n, b->batch);
     const int32_t *idx[2] = {b->stm, b->nstm};
     if (int rc = bt_ft_forward(s, &f, n->params + n->t_off[0], n->params + n->t_off[1], idx, n->hid, n->saved)) return rc;
     const float *x = n->hid;
     for (int k = 0; k < n->d.n_dense; k++) {
         bt_dense_desc q = dn_desc(n, k, b->batch);
-        if (int rc = bt_dense_forward(s, &q, n->params + n->t_off[2 + 2 * k], n->params + n->t_off[3 + 2 * k], x,
-                                      b->buckets, n->a[k]))
+        if (fuse_loss && k == n->d.n_dense - 1) {
+            // final layer + sigmoid-MSE + its gradient in one kernel; the partials are summed by the head backward
+            if (int rc = bt_internal_dense_forward_loss(
+                    s, &q, n->params + n->t_off[2 + 2 * k], n->params + n->t_off[3 + 2 * k], x, b->buckets, b->targets,
+                    n->d.use_entry_weights ? b->entry_weights : nullptr, n->a[k], n->grad_y, n->loss_partials,
+                    &n->n_loss_partials))
+                return rc;
+        } else if (int rc = bt_dense_forward(s, &q, n->params + n->t_off[2 + 2 * k], n->params + n->t_off[3 + 2 * k], x,
+                                             b->buckets, n->a[k]))
             return rc;
         x = n->a[k];
     }
@@ -167,6 +178,8 @@ int bt_net_create(const bt_net_desc *desc, int max_batch, float *ext_params, flo
     if ((rc = dmalloc(&n->g_hid, B * K0))) return fail(rc);
     if (desc->pairwise && (rc = dmalloc(&n->saved, B * desc->perspectives * desc->ft_out))) return fail(rc);
     if ((rc = dmalloc(&n->grad_y, B))) return fail(rc);
+    if ((rc = dmalloc(&n->gz0, B))) return fail(rc);
+    if ((rc = dmalloc(&n->loss_partials, 1024))) return fail(rc);
     for (int k = 0; k < desc->n_dense; k++) {
         if ((rc = dmalloc(&n->a[k], B * desc->dense_out[k]))) return fail(rc);
         if ((rc = dmalloc(&n->ga[k], B * desc->dense_out[k]))) return fail(rc);
@@ -195,6 +208,7 @@ int bt_net_destroy(bt_net *n) {
     if (n->own_params) bt_free(n->params);
     if (n->own_grads) bt_free(n->grads);
     bt_free(n->mom), bt_free(n->vel), bt_free(n->hid), bt_free(n->g_hid), bt_free(n->saved), bt_free(n->grad_y);
+    bt_free(n->gz0), bt_free(n->loss_partials);
     for (int k = 0; k < BT_MAX_DENSE; k++) bt_free(n->a[k]), bt_free(n->ga[k]);
     bt_free(n->ft_ws), bt_free(n->dense_ws);
     if (n->ev_fork) (void)hipEventDestroy(n->ev_fork);
@@ -220,7 +234,7 @@ int bt_net_set_adamw(bt_net *n, int t, float decay, float beta1, float beta2, fl
 int bt_net_forward(bt_net *n, void *stream, const bt_batch *b, float *out_dev, float *loss_sum_dev) {
     if (int rc = check_batch(n, b, "bt_net_forward")) return rc;
     hipStream_t s = bt_stream(stream);
-    if (int rc = forward_impl(n, s, b)) return rc;
+    if (int rc = forward_impl(n, s, b, false)) return rc;
     const float *y = n->a[n->d.n_dense - 1];
     if (out_dev) BT_HIP(hipMemcpyAsync(out_dev, y, sizeof(float) * b->batch, hipMemcpyDeviceToDevice, s));
     if (loss_sum_dev)
@@ -240,22 +254,41 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
     BT_HIP(hipStreamWaitEvent(n->side, n->ev_fork, 0));
     if (int rc = bt_ft_build_index(n->side, &f, idx, n->ft_ws, n->ft_ws_bytes)) return rc;
     BT_HIP(hipEventRecord(n->ev_index, n->side));
-    if (int rc = forward_impl(n, s, b)) return rc;
     const int L = n->d.n_dense;
-    if (int rc = bt_sigmoid_mse(s, b->batch, n->a[L - 1], b->targets,
-                                n->d.use_entry_weights ? b->entry_weights : nullptr, loss_sum_dev, n->grad_y))
-        return rc;
+    // fusion decisions (shape-dependent, see dense.hip / ft.hip): loss into the final head's forward, the head's dX
+    // into the FT backward staging
+    bt_dense_desc q_last = dn_desc(n, L - 1, b->batch), q0 = dn_desc(n, 0, b->batch);
+    const bool fuse_loss = bt_internal_dense_forward_loss_ok(&q_last) && bt_internal_dense_head_ok(&q_last);
+    const bool fuse_ft = bt_internal_dense_head_ok(&q0) && bt_internal_ft_fused_ok(&f, q0.buckets);
+    if (int rc = forward_impl(n, s, b, fuse_loss)) return rc;
+    if (!fuse_loss)
+        if (int rc = bt_sigmoid_mse(s, b->batch, n->a[L - 1], b->targets,
+                                    n->d.use_entry_weights ? b->entry_weights : nullptr, loss_sum_dev, n->grad_y))
+            return rc;
     for (int k = L - 1; k >= 0; k--) {
         bt_dense_desc q = dn_desc(n, k, b->batch);
         const float *x = (k == 0) ? n->hid : n->a[k - 1];
         const float *gy = (k == L - 1) ? n->grad_y : n->ga[k];
         float *gx = (k == 0) ? n->g_hid : n->ga[k - 1];
-        if (int rc = bt_dense_backward(s, &q, n->params + n->t_off[2 + 2 * k], x, b->buckets, n->a[k], gy,
-                                       n->grads + n->t_off[2 + 2 * k], n->grads + n->t_off[3 + 2 * k], gx, n->dense_ws,
-                                       n->dense_ws_bytes))
+        float *dwk = n->grads + n->t_off[2 + 2 * k], *dbk = n->grads + n->t_off[3 + 2 * k];
+        const float *wk = n->params + n->t_off[2 + 2 * k];
+        if (bt_internal_dense_head_ok(&q)) {
+            const bool ft_here = (k == 0) && fuse_ft;
+            const bool loss_here = (k == L - 1) && fuse_loss;
+            if (int rc = bt_internal_dense_backward_head(s, &q, wk, x, b->buckets, n->a[k], gy, dwk, dbk,
+                                                         ft_here ? nullptr : gx, ft_here ? n->gz0 : nullptr,
+                                                         loss_here ? n->loss_partials : nullptr, n->n_loss_partials,
+                                                         loss_sum_dev, n->dense_ws, n->dense_ws_bytes))
+                return rc;
+        } else if (int rc = bt_dense_backward(s, &q, wk, x, b->buckets, n->a[k], gy, dwk, dbk, gx, n->dense_ws,
+                                              n->dense_ws_bytes))
             return rc;
     }
     BT_HIP(hipStreamWaitEvent(s, n->ev_index, 0));  // join
+    if (fuse_ft)
+        return bt_internal_ft_backward_fused(s, &f, n->gz0, n->params + n->t_off[2],
+                                             n->d.dense_bucketed[0] ? b->buckets : nullptr, q0.buckets, n->hid, n->saved,
+                                             n->grads + n->t_off[0], n->grads + n->t_off[1], n->ft_ws, n->ft_ws_bytes);
     return bt_ft_backward_prebuilt(s, &f, n->g_hid, n->hid, n->saved, n->grads + n->t_off[0], n->grads + n->t_off[1],
                                    n->ft_ws, n->ft_ws_bytes);
 }
