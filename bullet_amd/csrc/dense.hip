@@ -284,6 +284,8 @@ __global__ __launch_bounds__(DF_THREADS) void dense_fwd_small(const float *__res
     }
 }
 
+constexpr int DBS_RANGE = 128;  // positions per workgroup in dense_bwd_small
+
 // Backward for out == 1 heads (one selected row per position): every thread owns 4 input columns for
 // ALL bucket rows in registers; the bucket select becomes a wave-uniform multiplier (gz or 0), so dW,
 // dbias and dX come out of one pass over x with no LDS and no atomics. Positions are visited in
@@ -320,23 +322,41 @@ __global__ __launch_bounds__(256) void dense_bwd_small(const float *__restrict__
         }
     }
     const int b0 = blockIdx.y * range, b1 = min(d.batch, b0 + range);
-    const float4 *x4 = reinterpret_cast<const float4 *>(x);
-    float4 *gx4 = reinterpret_cast<float4 *>(grad_x);
-#pragma unroll 4
-    for (int b = b0; b < b1; b++) {
-        const int bk = (d.buckets > 1) ? bucket[b] : 0;
+    const int nb = b1 - b0;
+    // per-position scalars (gz, bucket) staged once in LDS: the position loop then has no dependent global loads
+    __shared__ float s_gz[DBS_RANGE];
+    __shared__ int s_bk[DBS_RANGE];
+    for (int t = threadIdx.x; t < nb; t += blockDim.x) {
+        const int b = b0 + t;
         const float gz = grad_y[b] * bt_act_deriv(d.act, y[b]);
-        const float4 xv = active ? x4[(size_t)b * in4 + c4] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        float4 gx = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        s_gz[t] = gz;
+        s_bk[t] = (d.buckets > 1) ? bucket[b] : 0;
+        if (gz_out && blockIdx.x == 0) gz_out[b] = gz;
+    }
+    __syncthreads();
+    const float4 *x4 = reinterpret_cast<const float4 *>(x) + (size_t)b0 * in4 + c4;
+    float4 *gx4 = grad_x ? reinterpret_cast<float4 *>(grad_x) + (size_t)b0 * in4 + c4 : nullptr;
+    constexpr int U = 8;
+    for (int t0 = 0; t0 < nb; t0 += U) {
+        float4 xv[U];
 #pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-            const float m = (r == bk) ? gz : 0.0f;  // SelectPad: zeros outside the selected row
-            acc[r].x += m * xv.x, acc[r].y += m * xv.y, acc[r].z += m * xv.z, acc[r].w += m * xv.w;
-            gx.x += m * wr[r].x, gx.y += m * wr[r].y, gx.z += m * wr[r].z, gx.w += m * wr[r].w;
-            accb[r] += m;
+        for (int u = 0; u < U; u++)
+            xv[u] = (active && t0 + u < nb) ? x4[(size_t)(t0 + u) * in4] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (t0 + u >= nb) break;
+            const int bk = s_bk[t0 + u];
+            const float gz = s_gz[t0 + u];
+            float4 gx = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const float m = (r == bk) ? gz : 0.0f;  // SelectPad: zeros outside the selected row
+                acc[r].x += m * xv[u].x, acc[r].y += m * xv[u].y, acc[r].z += m * xv[u].z, acc[r].w += m * xv[u].w;
+                gx.x += m * wr[r].x, gx.y += m * wr[r].y, gx.z += m * wr[r].z, gx.w += m * wr[r].w;
+                accb[r] += m;
+            }
+            if (gx4 && active) gx4[(size_t)(t0 + u) * in4] = gx;
         }
-        if (grad_x && active) gx4[(size_t)b * in4 + c4] = gx;
-        if (gz_out && blockIdx.x == 0 && threadIdx.x == 0) gz_out[b] = gz;
     }
     if (active) {
         float *pw = part_w + (size_t)blockIdx.y * rows * d.in + (size_t)rows * (c4 * 4);
@@ -351,7 +371,6 @@ __global__ __launch_bounds__(256) void dense_bwd_small(const float *__restrict__
     }
 }
 
-constexpr int DBS_RANGE = 128;  // positions per workgroup in dense_bwd_small
 
 bool dense_fwd_small_ok(const bt_dense_desc *d) {
     const int rows = d->out * d->buckets;

@@ -208,7 +208,7 @@ __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t 
                 cnt[(size_t)w2 * cols + f] = run;
                 run += v;
             }
-            while (run & 3) my_sorted[run++] = (uint16_t)FT_CHUNK;  // pad the run; id FT_CHUNK = "add nothing"
+            while (run & 3) my_sorted[run++] = (uint16_t)(FT_CHUNK << 7);  // pad the run; id FT_CHUNK = "add nothing"
         }
         if (f_hi == cols && f_lo < cols) my_offs[cols] = run;
     }
@@ -236,7 +236,7 @@ __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t 
             const int rank = __popcll(peers & lt_mask);
             const int count = __popcll(peers);
             const uint32_t base = start[j];
-            my_sorted[base + rank] = (uint16_t)e;
+            my_sorted[base + rank] = (uint16_t)(e << 7);  // stored as the byte offset of the entry's 128-B tile row
             if (rank == count - 1) start[j] = base + count;
         }
     }
@@ -299,8 +299,9 @@ __global__ void ft_bwd_gather(const float *__restrict__ g, const uint16_t *__res
             const size_t ebase = (size_t)k * d.batch + (size_t)cb * FT_CHUNK;
             const uint16_t *lst = sorted + (size_t)c * ft_sorted_cap(d.nnz, d.cols);
             for (uint32_t q2 = s; q2 < e; q2++) {
-                if (lst[q2] >= FT_CHUNK) break;  // run padding
-                Vec<VEC> x = vload<VEC>(g + (ebase + lst[q2]) * d.rows + r0);
+                const int el = lst[q2] >> 7;
+                if (el >= FT_CHUNK) break;  // run padding
+                Vec<VEC> x = vload<VEC>(g + (ebase + el) * d.rows + r0);
 #pragma unroll
                 for (int q = 0; q < VEC; q++) acc.v[q] += x.v[q];
             }
@@ -618,18 +619,25 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
             const uint32_t s = offl[f], e = offl[f + 1];
             if (s == e) continue;
             float2 a = make_float2(0.0f, 0.0f);
-            const char *gb = reinterpret_cast<const char *>(gt) + sub * 8;
-            // runs are padded to multiples of 4 with the zero-row id: no per-element predicates
+            const char *gb = reinterpret_cast<const char *>(gt);
+            const unsigned lane_off = sub * 8;
+            // runs are 4-aligned and padded with the zero-row offset: no per-element predicates. The list holds
+            // byte offsets (entry * 128) as u16 pairs, so an address is "packed half + lane offset" (one SDWA add);
+            // the next block's offsets are fetched while this block's rows are in flight.
+            uint2 w = *reinterpret_cast<const uint2 *>(srt + s);
             for (uint32_t q = s; q < e; q += 4) {
-                const int i0 = srt[q], i1 = srt[q + 1], i2 = srt[q + 2], i3 = srt[q + 3];
-                const float2 v0 = *reinterpret_cast<const float2 *>(gb + i0 * (LDS_RT * 4));
-                const float2 v1 = *reinterpret_cast<const float2 *>(gb + i1 * (LDS_RT * 4));
-                const float2 v2 = *reinterpret_cast<const float2 *>(gb + i2 * (LDS_RT * 4));
-                const float2 v3 = *reinterpret_cast<const float2 *>(gb + i3 * (LDS_RT * 4));
+                const uint32_t qn = min(q + 4, e - 4);
+                const uint64_t wn64 = *(const volatile __attribute__((address_space(3))) uint64_t *)(srt + qn);  // volatile: stays in this iteration
+                const uint2 wn = make_uint2((uint32_t)wn64, (uint32_t)(wn64 >> 32));
+                const float2 v0 = *reinterpret_cast<const float2 *>(gb + ((w.x & 0xffffu) + lane_off));
+                const float2 v1 = *reinterpret_cast<const float2 *>(gb + ((w.x >> 16) + lane_off));
+                const float2 v2 = *reinterpret_cast<const float2 *>(gb + ((w.y & 0xffffu) + lane_off));
+                const float2 v3 = *reinterpret_cast<const float2 *>(gb + ((w.y >> 16) + lane_off));
                 a.x += v0.x, a.y += v0.y;
                 a.x += v1.x, a.y += v1.y;
                 a.x += v2.x, a.y += v2.y;
                 a.x += v3.x, a.y += v3.y;
+                w = wn;
             }
             float2 *dst = reinterpret_cast<float2 *>(acc + f * LDS_RT + sub * 2);  // owned by this group only
             float2 cur = *dst;
