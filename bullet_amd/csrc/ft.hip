@@ -354,40 +354,50 @@ __device__ __forceinline__ int tile_row(bool pair, int rt, int half_rows, int lo
     return (local4 < 16) ? rt * 16 + local4 : half_rows + rt * 16 + (local4 - 16);
 }
 
-// 8 gathers issued back to back (independent LDS reads in flight), then 8 ordered adds.
-// `reg` holds byte offsets f * 128 of this lane's index slots; row_share<n>(reg) + lane_off is a single
-// v_add_u32 with a DPP source operand, so one gather costs 2 VALU (address, packed add) + 1 ds_read_b64.
-template <int N0>
-__device__ __forceinline__ void fwd_block8(const char *wl, int reg, int lane_off, float2 &acc) {
-    const int a0 = row_share<N0 + 0>(reg) + lane_off, a1 = row_share<N0 + 1>(reg) + lane_off,
-              a2 = row_share<N0 + 2>(reg) + lane_off, a3 = row_share<N0 + 3>(reg) + lane_off,
-              a4 = row_share<N0 + 4>(reg) + lane_off, a5 = row_share<N0 + 5>(reg) + lane_off,
-              a6 = row_share<N0 + 6>(reg) + lane_off, a7 = row_share<N0 + 7>(reg) + lane_off;
-    const float2 v0 = *reinterpret_cast<const float2 *>(wl + a0);
-    const float2 v1 = *reinterpret_cast<const float2 *>(wl + a1);
-    const float2 v2 = *reinterpret_cast<const float2 *>(wl + a2);
-    const float2 v3 = *reinterpret_cast<const float2 *>(wl + a3);
-    const float2 v4 = *reinterpret_cast<const float2 *>(wl + a4);
-    const float2 v5 = *reinterpret_cast<const float2 *>(wl + a5);
-    const float2 v6 = *reinterpret_cast<const float2 *>(wl + a6);
-    const float2 v7 = *reinterpret_cast<const float2 *>(wl + a7);
-    acc.x += v0.x, acc.y += v0.y;
-    acc.x += v1.x, acc.y += v1.y;
-    acc.x += v2.x, acc.y += v2.y;
-    acc.x += v3.x, acc.y += v3.y;
-    acc.x += v4.x, acc.y += v4.y;
-    acc.x += v5.x, acc.y += v5.y;
-    acc.x += v6.x, acc.y += v6.y;
-    acc.x += v7.x, acc.y += v7.y;
-}
+typedef unsigned lds_u4_t __attribute__((ext_vector_type(4)));
 
-template <bool PAIR, int NREG>
+__device__ __forceinline__ void add4(float4 &a, const float4 &v) { a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w; }
+
+// Forward: 8 lanes x float4 cover the 32-row tile of one position-perspective ("entry"), so a wave sums 8 entries
+// at a time. The wave's index lists are validated once (stop rule, write.rs:231), turned into byte offsets of
+// tile rows (masked slots -> the zero row) and parked in a per-wave LDS strip; the gather loop then costs, per 4
+// features, 1 ds_read_b128 of offsets + 4 address adds + 4 ds_read_b128 gathers + 8 packed adds: 0.75 VALU per
+// summed element. The sum runs over the features in list order, like the reference's loop (sparse.rs:100-113).
+constexpr int FWD_EPW = 8;  // entries per wave per pass
+
+// ds_read_b128 is served in four 16-lane groups, {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32; only
+// lanes of one group can bank-conflict. Giving each group two whole 128-B rows (instead of four half rows)
+// makes a conflict a coin flip on the two rows' parity: 1.5 LDS cycles per group on average instead of 1.75.
+__device__ __forceinline__ void fwd_gather_slot(int lane, int &entry, int &slot) {
+    const int m = lane & 31, h = lane >> 5;
+    int q, sl;
+    if (m < 4) q = 0, sl = m;
+    else if (m < 12) q = 2, sl = m - 4;
+    else if (m < 16) q = 0, sl = m - 8;
+    else if (m < 20) q = 3, sl = m - 16;
+    else if (m < 28) q = 1, sl = m - 20;
+    else q = 3, sl = m - 24;
+    entry = h * 4 + q, slot = sl;
+}
+__device__ __forceinline__ int fwd_gather_lane(int entry, int slot) {
+    const int q = entry & 3, h = entry >> 2;
+    int m;
+    if (q == 0) m = slot < 4 ? slot : slot + 8;
+    else if (q == 1) m = 20 + slot;
+    else if (q == 2) m = 4 + slot;
+    else m = slot < 4 ? 16 + slot : 24 + slot;
+    return h * 32 + m;
+}
+__host__ __device__ constexpr int fwd_strip_words(int nround) { return nround * 32 + 4; }  // +4: bank skew
+
+template <bool PAIR, bool ALIGNED4, int NROUND>
 __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restrict__ w, const float *__restrict__ bias,
                                                           const int32_t *__restrict__ idx0,
                                                           const int32_t *__restrict__ idx1, float *__restrict__ out,
                                                           float *__restrict__ saved, bt_ft_desc d, int ntiles,
                                                           int entries_per_wg) {
     extern __shared__ float wl[];  // [(cols + 1)][32]; row `cols` is all zero (target of masked slots)
+    constexpr int SS = fwd_strip_words(NROUND);
     const int rt = blockIdx.x % ntiles, grp = blockIdx.x / ntiles;
     const int half_rows = d.rows / 2;
     for (int q = threadIdx.x; q < d.cols * 8; q += LDS_THREADS) {
@@ -400,72 +410,128 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sub = lane & 15, eslot = lane >> 4;
-    const int row = tile_row(PAIR, rt, half_rows, sub * 2);
-    float2 bv = make_float2(0.0f, 0.0f);
-    if (bias) bv = *reinterpret_cast<const float2 *>(bias + row);
-    // entries e = k*batch + b as 32-bit ints (host checks n_inputs*batch < 2^31); n_inputs <= 2, so the
+    // two lane -> (entry, part) maps: contiguous 8-lane groups while the index lists are decoded (ballots),
+    // the bank-friendly map of fwd_gather_slot while rows are gathered, summed and stored
+    const int sub = lane & 7, eslot = lane >> 3;
+    int ge, gs;
+    fwd_gather_slot(lane, ge, gs);
+    uint32_t *wstrip = reinterpret_cast<uint32_t *>(wl + (d.cols + 1) * LDS_RT) + wave * FWD_EPW * SS;
+    uint32_t *dstrip = wstrip + eslot * SS;        // written by the decode map
+    const uint32_t *strip = wstrip + ge * SS;      // read by the gather map
+    const int row = tile_row(PAIR, rt, half_rows, gs * 4);
+    float4 bv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (bias) bv = *reinterpret_cast<const float4 *>(bias + row);
+    // entries e = k*batch + b as 32-bit ints (host checks n_inputs*batch < 2^30); n_inputs <= 2, so the
     // (k, b) split is a compare + subtract -- no integer division in the hot loop
     const int E = d.n_inputs * d.batch;
     const int e_begin = grp * entries_per_wg;
     const int e_end = min(E, e_begin + entries_per_wg);
     const int out_w = PAIR ? half_rows : d.rows;
+    constexpr int PASS = (LDS_THREADS / 64) * FWD_EPW;
 
-    // raw index registers of the NEXT iteration are loaded while the current one is being summed
-    // Unconditional, clamped loads (validity is applied at decode time): with no branch around them the
-    // compiler keeps them in flight behind a counted s_waitcnt instead of draining with vmcnt(0).
-    auto load_idx = [&](int eb2, int(&r)[NREG]) {
+    // raw indices of the NEXT pass are loaded while the current one is being summed. Unconditional, clamped
+    // loads (validity is applied at decode time): with no branch around them the compiler keeps them in
+    // flight behind a counted s_waitcnt instead of draining with vmcnt(0).
+    auto load_idx = [&](int eb2, int(&r)[NROUND][4]) {
         const int e2 = min(eb2 + eslot, E - 1);
         const int k2 = (e2 >= d.batch) ? 1 : 0;
         const int b2 = e2 - k2 * d.batch;
         const int32_t *ip = (k2 == 0 ? idx0 : idx1) + (size_t)b2 * d.nnz;
 #pragma unroll
-        for (int q = 0; q < NREG; q++) r[q] = ip[min(q * 16 + sub, d.nnz - 1)];
+        for (int q = 0; q < NROUND; q++) {
+            if constexpr (ALIGNED4) {
+                const int4 v = *reinterpret_cast<const int4 *>(ip + min(q * 32 + sub * 4, d.nnz - 4));
+                r[q][0] = v.x, r[q][1] = v.y, r[q][2] = v.z, r[q][3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) r[q][j] = ip[min(q * 32 + sub * 4 + j, d.nnz - 1)];
+            }
+        }
     };
-    int nxt[NREG];
-    load_idx(e_begin + wave * 4, nxt);
-    for (int eb = e_begin + wave * 4; eb < e_end; eb += (LDS_THREADS / 64) * 4) {
-        const int e = eb + eslot;
+    int nxt[NROUND][4];
+    load_idx(e_begin + wave * FWD_EPW, nxt);
+    for (int eb = e_begin + wave * FWD_EPW; eb < e_end; eb += PASS) {
+        int reg[NROUND][4];
+#pragma unroll
+        for (int q = 0; q < NROUND; q++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) reg[q][j] = nxt[q][j];
+        load_idx(eb + PASS, nxt);
+        // decode: slot p is masked iff any slot <= p of the same entry is invalid
+        bool dead = eb + eslot >= e_end;
+        int nblk = 0;  // wave-uniform: 4-slot blocks that hold a live slot for at least one entry
+#pragma unroll
+        for (int q = 0; q < NROUND; q++) {
+            bool inv[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                // ALIGNED4 loads are clamped per block of 4, so a clamped block repeats data of slots < nnz
+                const int p = q * 32 + sub * 4 + j;
+                inv[j] = (p >= d.nnz) || reg[q][j] < 0 || reg[q][j] >= d.cols;
+            }
+            const bool any = inv[0] | inv[1] | inv[2] | inv[3];
+            const unsigned m = (unsigned)(__ballot(any) >> (eslot * 8)) & 0xFFu;
+            bool kill = dead || (m & ((1u << sub) - 1u));
+            const unsigned long long open = __ballot(!(kill || inv[0]));  // blocks whose first slot is live
+            lds_u4_t o;
+            kill |= inv[0], o.x = (unsigned)(kill ? d.cols : reg[q][0]) * (LDS_RT * 4);
+            kill |= inv[1], o.y = (unsigned)(kill ? d.cols : reg[q][1]) * (LDS_RT * 4);
+            kill |= inv[2], o.z = (unsigned)(kill ? d.cols : reg[q][2]) * (LDS_RT * 4);
+            kill |= inv[3], o.w = (unsigned)(kill ? d.cols : reg[q][3]) * (LDS_RT * 4);
+            *reinterpret_cast<lds_u4_t *>(dstrip + q * 32 + sub * 4) = o;
+            dead |= (m != 0);
+            unsigned fold = (unsigned)open | (unsigned)(open >> 32);
+            fold |= fold >> 16;
+            fold |= fold >> 8;
+            nblk += __popc(fold & 0xFFu);  // live blocks form a prefix in every entry, so the union is a prefix
+        }
+        __builtin_amdgcn_wave_barrier();  // the strips are private to this wave; LDS executes a wave's ops in order
+
+        // 8 features per trip (an odd tail block reads masked slots = the zero row)
+        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const char *wlb = reinterpret_cast<const char *>(wl) + gs * 16;
+        const int ntrip = (nblk + 1) >> 1;
+        if (ntrip > 0) {
+            lds_u4_t ia = *reinterpret_cast<const lds_u4_t *>(strip), ib = *reinterpret_cast<const lds_u4_t *>(strip + 4);
+            for (int t = 0; t < ntrip; t++) {
+                // volatile + LDS address space: the next trip's offsets are fetched in THIS iteration, ahead of
+                // the gathers, so a trip pays one LDS latency instead of two
+                typedef const volatile __attribute__((address_space(3))) lds_u4_t *vstrip_t;
+                const int tn = min(t + 1, ntrip - 1) * 8;
+                const lds_u4_t na = *(vstrip_t)(strip + tn), nb = *(vstrip_t)(strip + tn + 4);
+                const float4 v0 = *reinterpret_cast<const float4 *>(wlb + ia.x);
+                const float4 v1 = *reinterpret_cast<const float4 *>(wlb + ia.y);
+                const float4 v2 = *reinterpret_cast<const float4 *>(wlb + ia.z);
+                const float4 v3 = *reinterpret_cast<const float4 *>(wlb + ia.w);
+                const float4 v4 = *reinterpret_cast<const float4 *>(wlb + ib.x);
+                const float4 v5 = *reinterpret_cast<const float4 *>(wlb + ib.y);
+                const float4 v6 = *reinterpret_cast<const float4 *>(wlb + ib.z);
+                const float4 v7 = *reinterpret_cast<const float4 *>(wlb + ib.w);
+                add4(acc, v0), add4(acc, v1), add4(acc, v2), add4(acc, v3);
+                add4(acc, v4), add4(acc, v5), add4(acc, v6), add4(acc, v7);
+                ia = na, ib = nb;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int e = eb + ge;
         const bool live = e < e_end;
         const int k = (live && e >= d.batch) ? 1 : 0;
         const int b = live ? e - k * d.batch : 0;
-        int reg[NREG];
-#pragma unroll
-        for (int q = 0; q < NREG; q++) reg[q] = nxt[q];
-        load_idx(eb + (LDS_THREADS / 64) * 4, nxt);
-        int nvalid = d.nnz;
-#pragma unroll
-        for (int q = NREG - 1; q >= 0; q--) {
-            const int p = q * 16 + sub;
-            const int j = reg[q];
-            const bool inval = !live || (p >= d.nnz) || j < 0 || j >= d.cols;
-            const unsigned m = (unsigned)((__ballot(inval) >> (eslot * 16)) & 0xFFFFull);
-            if (m) nvalid = q * 16 + __ffs((int)m) - 1;  // descending q: the smallest position wins
-        }
-#pragma unroll
-        for (int q = 0; q < NREG; q++)  // stop rule (write.rs:231): masked slots read the zero row
-            reg[q] = ((q * 16 + sub >= nvalid) ? d.cols : reg[q]) * (LDS_RT * 4);
-        const int maxcnt = max(max(__builtin_amdgcn_readlane(nvalid, 0), __builtin_amdgcn_readlane(nvalid, 16)),
-                               max(__builtin_amdgcn_readlane(nvalid, 32), __builtin_amdgcn_readlane(nvalid, 48)));
-        float2 acc = make_float2(0.0f, 0.0f);
-#pragma unroll
-        for (int q = 0; q < NREG; q++) {
-            // wave-uniform skips at 8-slot granularity; masked slots inside a block read the zero row
-            if (q * 16 < maxcnt) fwd_block8<0>(reinterpret_cast<const char *>(wl), reg[q], sub * 8, acc);
-            if (q * 16 + 8 < maxcnt) fwd_block8<8>(reinterpret_cast<const char *>(wl), reg[q], sub * 8, acc);
-        }
-        float2 c = make_float2(bt_act_fwd(d.act, acc.x + bv.x), bt_act_fwd(d.act, acc.y + bv.y));
+        float4 c = make_float4(bt_act_fwd(d.act, acc.x + bv.x), bt_act_fwd(d.act, acc.y + bv.y),
+                               bt_act_fwd(d.act, acc.z + bv.z), bt_act_fwd(d.act, acc.w + bv.w));
         if constexpr (PAIR) {
-            // lanes sub and sub^8 hold the two factors of the same output column
-            const float ox = __shfl_xor(c.x, 8, 16), oy = __shfl_xor(c.y, 8, 16);
+            // the lane holding part gs^4 of the same entry has the other factors of the same output columns
+            const int partner = fwd_gather_lane(ge, gs ^ 4);
+            const float4 o = make_float4(__shfl(c.x, partner), __shfl(c.y, partner), __shfl(c.z, partner),
+                                         __shfl(c.w, partner));
             if (live) {
-                *reinterpret_cast<float2 *>(saved + (size_t)e * d.rows + row) = c;
-                if (sub < 8)
-                    *reinterpret_cast<float2 *>(out + (size_t)b * d.out_ld + (size_t)k * out_w + rt * 16 + sub * 2) =
-                        make_float2(c.x * ox, c.y * oy);
+                *reinterpret_cast<float4 *>(saved + (size_t)e * d.rows + row) = c;
+                if (gs < 4)
+                    *reinterpret_cast<float4 *>(out + (size_t)b * d.out_ld + (size_t)k * out_w + rt * 16 + gs * 4) =
+                        make_float4(c.x * o.x, c.y * o.y, c.z * o.z, c.w * o.w);
             }
         } else {
-            if (live) *reinterpret_cast<float2 *>(out + (size_t)b * d.out_ld + (size_t)k * out_w + row) = c;
+            if (live) *reinterpret_cast<float4 *>(out + (size_t)b * d.out_ld + (size_t)k * out_w + row) = c;
         }
     }
 }
@@ -740,7 +806,8 @@ int ft_plan(const bt_ft_desc *d, FtPlan *p) {
     p->off_bpart = o;
     o += bt_align((size_t)p->bias_blocks * d->rows * sizeof(float));
     // LDS-resident path: 32-row tiles, table tile + staging must fit the 160 KiB LDS
-    p->lds_fwd_bytes = (size_t)(d->cols + 1) * LDS_RT * sizeof(float);
+    p->lds_fwd_bytes = (size_t)(d->cols + 1) * LDS_RT * sizeof(float) +
+                       (size_t)(LDS_THREADS / 64) * FWD_EPW * fwd_strip_words((d->nnz + 31) / 32) * sizeof(uint32_t);
     p->lds_bwd_bytes = ((size_t)d->cols * LDS_RT + (FT_CHUNK + 1) * LDS_RT) * sizeof(float) +
                        (size_t)((d->cols + 2) & ~1) * sizeof(uint32_t) + (size_t)ft_sorted_cap(d->nnz, d->cols) * sizeof(uint16_t);
     p->lds_path = (p->vec == 4) && (d->rows % LDS_RT == 0) && p->lds_bwd_bytes <= 160 * 1024 &&
@@ -847,27 +914,31 @@ int bt_ft_forward(void *stream, const bt_ft_desc *d, const float *w, const float
         int G = 256 / p.ntiles;
         if (G < 1) G = 1;
         long long epw = (E + G - 1) / G;
-        epw = (epw + 63) / 64 * 64;  // whole passes of 16 waves x 4 entries
+        epw = (epw + 127) / 128 * 128;  // whole passes of 16 waves x 8 entries
         G = (int)((E + epw - 1) / epw);
-        const int nreg = (d->nnz + 15) / 16;
+        const int nround = (d->nnz + 31) / 32;
+        const bool al4 = d->nnz % 4 == 0 && (reinterpret_cast<uintptr_t>(i0) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(i1) & 15) == 0;
         dim3 lgrid(p.ntiles * G), lblock(LDS_THREADS);
-#define FWD_LDS(PAIR, NREG)                                                                                     \
+#define FWD_LDS(PAIR, AL4, NROUND)                                                                              \
     do {                                                                                                        \
-        if (int rc = set_lds(ft_fwd_lds<PAIR, NREG>, p.lds_fwd_bytes)) return rc;                               \
-        BT_LAUNCH(BTK_FT_FWD_LDS, s, (ft_fwd_lds<PAIR, NREG>), lgrid, lblock, p.lds_fwd_bytes, w, bias, i0, i1, out, \
-                  saved, *d, p.ntiles, (int)epw);                                                               \
+        if (int rc = set_lds(ft_fwd_lds<PAIR, AL4, NROUND>, p.lds_fwd_bytes)) return rc;                        \
+        BT_LAUNCH(BTK_FT_FWD_LDS, s, (ft_fwd_lds<PAIR, AL4, NROUND>), lgrid, lblock, p.lds_fwd_bytes, w, bias, i0, i1, \
+                  out, saved, *d, p.ntiles, (int)epw);                                                          \
+    } while (0)
+#define FWD_LDS2(PAIR, AL4)                                                                                     \
+    do {                                                                                                        \
+        if (nround == 1) FWD_LDS(PAIR, AL4, 1);                                                                 \
+        else FWD_LDS(PAIR, AL4, 2);                                                                             \
     } while (0)
         if (d->pairwise) {
-            if (nreg == 1) FWD_LDS(true, 1);
-            else if (nreg == 2) FWD_LDS(true, 2);
-            else if (nreg == 3) FWD_LDS(true, 3);
-            else FWD_LDS(true, 4);
+            if (al4) FWD_LDS2(true, true);
+            else FWD_LDS2(true, false);
         } else {
-            if (nreg == 1) FWD_LDS(false, 1);
-            else if (nreg == 2) FWD_LDS(false, 2);
-            else if (nreg == 3) FWD_LDS(false, 3);
-            else FWD_LDS(false, 4);
+            if (al4) FWD_LDS2(false, true);
+            else FWD_LDS2(false, false);
         }
+#undef FWD_LDS2
 #undef FWD_LDS
         BT_LAUNCH_CHECK();
         return BT_OK;
