@@ -112,6 +112,31 @@ __device__ __forceinline__ float bt_act_fwd(int act, float v) {
     }
 }
 
+// 4 derivatives behind one switch; raw v_sqrt_f32 (same result as sqrtf for normal inputs; denormal outputs,
+// |o| < 1.2e-38, give 0 instead of ~1e-19 -- far below anything the gradient keeps)
+__device__ __forceinline__ float4 bt_act_deriv4(int act, float4 o) {
+    auto pos = [](float v) { return v > 0.0f ? 1.0f : 0.0f; };
+    switch (act) {
+    case BT_ACT_RELU: return make_float4(pos(o.x), pos(o.y), pos(o.z), pos(o.w));
+    case BT_ACT_CRELU:
+        return make_float4(pos(o.x) * pos(1.0f - o.x), pos(o.y) * pos(1.0f - o.y), pos(o.z) * pos(1.0f - o.z),
+                           pos(o.w) * pos(1.0f - o.w));
+    case BT_ACT_SCRELU: {
+        const float hx = (pos(o.x) * pos(1.0f - o.x)) * __builtin_amdgcn_sqrtf(o.x);
+        const float hy = (pos(o.y) * pos(1.0f - o.y)) * __builtin_amdgcn_sqrtf(o.y);
+        const float hz = (pos(o.z) * pos(1.0f - o.z)) * __builtin_amdgcn_sqrtf(o.z);
+        const float hw = (pos(o.w) * pos(1.0f - o.w)) * __builtin_amdgcn_sqrtf(o.w);
+        return make_float4(hx + hx, hy + hy, hz + hz, hw + hw);
+    }
+    case BT_ACT_SQRRELU: {
+        const float hx = pos(o.x) * __builtin_amdgcn_sqrtf(o.x), hy = pos(o.y) * __builtin_amdgcn_sqrtf(o.y);
+        const float hz = pos(o.z) * __builtin_amdgcn_sqrtf(o.z), hw = pos(o.w) * __builtin_amdgcn_sqrtf(o.w);
+        return make_float4(hx + hx, hy + hy, hz + hz, hw + hw);
+    }
+    default: return make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    }
+}
+
 // derivative computed from the activation OUTPUT, composed exactly as dfo.rs does:
 // CReLU' = [o>0]*[1-o>0]; SCReLU' = half+half, half = CReLU'(o)*sqrt(o); SqrReLU' likewise with ReLU'.
 __device__ __forceinline__ float bt_act_deriv(int act, float o) {

@@ -133,6 +133,50 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float *__restri
     }
 }
 
+// same sums in the same order, four adjacent elements per thread (16-B loads; n % 4 == 0, 16-B aligned buffers)
+__global__ __launch_bounds__(256) void sum_partials4_kernel(const float *__restrict__ part, int nparts, size_t n4,
+                                                            float *__restrict__ out) {
+    __shared__ float4 red[8][32];
+    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const size_t t = (size_t)blockIdx.x * 32 + el;
+    const int per = (nparts + 7) / 8;
+    const int p0 = sl * per, p1 = min(nparts, p0 + per);
+    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (t < n4) {
+        const float4 *src = reinterpret_cast<const float4 *>(part) + t;
+        int p = p0;
+        for (; p + 8 <= p1; p += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = src[(size_t)(p + u) * n4];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s.x += v[u].x, s.y += v[u].y, s.z += v[u].z, s.w += v[u].w;
+        }
+        for (; p < p1; p++) {
+            const float4 v = src[(size_t)p * n4];
+            s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+        }
+    }
+    red[sl][el] = s;
+    __syncthreads();
+    if (sl == 0 && t < n4) {
+        float4 r = red[0][el];
+#pragma unroll
+        for (int i = 1; i < 8; i++) r.x += red[i][el].x, r.y += red[i][el].y, r.z += red[i][el].z, r.w += red[i][el].w;
+        reinterpret_cast<float4 *>(out)[t] = r;
+    }
+}
+
+int sum_partials_launch(hipStream_t s, const float *part, int nparts, size_t n, float *out) {
+    const bool v4 = n % 4 == 0 && ((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (v4)
+        BT_LAUNCH(BTK_SUM_PARTIALS, s, sum_partials4_kernel, dim3(bt_div_up(n / 4, 32)), dim3(256), 0, part, nparts, n / 4, out);
+    else
+        BT_LAUNCH(BTK_SUM_PARTIALS, s, sum_partials_kernel, dim3(bt_div_up(n, 32)), dim3(256), 0, part, nparts, n, out);
+    BT_LAUNCH_CHECK();
+    return BT_OK;
+}
+
 // ------------------------------------------------------------------ loss
 // single workgroup: fixed strided partial sums + fixed tree => deterministic loss
 __global__ __launch_bounds__(1024) void sigmoid_mse_kernel(int batch, const float *__restrict__ y,
@@ -286,39 +330,46 @@ __global__ __launch_bounds__(DF_THREADS) void dense_fwd_small(const float *__res
 
 constexpr int DBS_RANGE = 128;  // positions per workgroup in dense_bwd_small
 
-// Backward for out == 1 heads (one selected row per position): every thread owns 4 input columns for
-// ALL bucket rows in registers; the bucket select becomes a wave-uniform multiplier (gz or 0), so dW,
-// dbias and dX come out of one pass over x with no LDS and no atomics. Positions are visited in
-// ascending order inside a workgroup, workgroup partials are merged in order => deterministic.
-template <int ROWS>
-__global__ __launch_bounds__(256) void dense_bwd_small(const float *__restrict__ w, const float *__restrict__ x,
-                                                       const int32_t *__restrict__ bucket,
-                                                       const float *__restrict__ y,
-                                                       const float *__restrict__ grad_y,
-                                                       float *__restrict__ part_w, float *__restrict__ part_b,
-                                                       float *__restrict__ grad_x, bt_dense_desc d, int range,
-                                                       float *__restrict__ gz_out,
-                                                       const float *__restrict__ loss_partials, int n_loss_partials,
-                                                       float *__restrict__ loss_sum) {
+// Backward for out == 1 heads (one selected row per position): every thread owns 4 input columns and keeps
+// the dW accumulators of ALL bucket rows in registers. The bucket of a position is the same for every thread, so
+// it is read into an SGPR and the select (SelectPad backward: zeros outside the selected row) becomes a scalar
+// branch to the one row that changes: 4 FMAs per position. x is streamed with two batches of U loads in
+// flight (HBM-bound). Positions are visited in ascending order inside a workgroup and workgroup partials are
+// merged in order => deterministic. GX: also emit dX = gz * W[bucket] (skipped when the FT backward forms it itself).
+constexpr int DBS_CT = 256;  // column threads (float4 columns) per workgroup
+constexpr int DBS_SUB = 2;  // position sub-ranges of a workgroup (one per 256 threads), merged in order at the end
+template <int ROWS, bool GX>
+__global__ __launch_bounds__(DBS_CT * DBS_SUB) void dense_bwd_small(const float *__restrict__ w, const float *__restrict__ x,
+                                                                 const int32_t *__restrict__ bucket,
+                                                                 const float *__restrict__ y,
+                                                                 const float *__restrict__ grad_y,
+                                                                 float *__restrict__ part_w, float *__restrict__ part_b,
+                                                                 float *__restrict__ grad_x, bt_dense_desc d, int range,
+                                                                 float *__restrict__ gz_out,
+                                                                 const float *__restrict__ loss_partials,
+                                                                 int n_loss_partials, float *__restrict__ loss_sum) {
     const int rows = d.buckets;  // out == 1
     if (loss_partials && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         float t = 0.0f;  // fixed-order final sum of the forward kernel's loss partials
         for (int i = 0; i < n_loss_partials; i++) t += loss_partials[i];
         loss_sum[0] = t;
     }
+    const int ct = threadIdx.x % DBS_CT, sub = threadIdx.x / DBS_CT;
     const int in4 = d.in >> 2;
-    const int c4 = blockIdx.x * 256 + threadIdx.x;
-    const bool active = c4 < in4;
-    float4 wr[ROWS], acc[ROWS];
+    const int c4 = min((int)(blockIdx.x * DBS_CT + ct), in4 - 1);  // clamped: loads stay unconditional
+    const bool active = (int)(blockIdx.x * DBS_CT + ct) < in4;
+    float4 wr[GX ? ROWS : 1], acc[ROWS];
     float accb[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
         acc[r] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         accb[r] = 0.0f;
-        wr[r] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (active && r < rows) {
-            const float *wc = w + (size_t)rows * (c4 * 4) + r;
-            wr[r] = make_float4(wc[0], wc[rows], wc[2 * rows], wc[3 * rows]);
+        if constexpr (GX) {
+            wr[r] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (r < rows) {
+                const float *wc = w + (size_t)rows * (c4 * 4) + r;
+                wr[r] = make_float4(wc[0], wc[rows], wc[2 * rows], wc[3 * rows]);
+            }
         }
     }
     const int b0 = blockIdx.y * range, b1 = min(d.batch, b0 + range);
@@ -326,39 +377,88 @@ __global__ __launch_bounds__(256) void dense_bwd_small(const float *__restrict__
     // per-position scalars (gz, bucket) staged once in LDS: the position loop then has no dependent global loads
     __shared__ float s_gz[DBS_RANGE];
     __shared__ int s_bk[DBS_RANGE];
-    for (int t = threadIdx.x; t < nb; t += blockDim.x) {
-        const int b = b0 + t;
-        const float gz = grad_y[b] * bt_act_deriv(d.act, y[b]);
+    constexpr int RCH = 2048 / DBS_CT;  // rows merged per round (32 KiB of LDS)
+    __shared__ float4 red[RCH][DBS_CT];
+    __shared__ float redb[DBS_SUB][16];
+    for (int t = threadIdx.x; t < DBS_RANGE; t += blockDim.x) {
+        float gz = 0.0f;  // positions past the end contribute nothing
+        int bk = 0;
+        if (t < nb) {
+            const int b = b0 + t;
+            gz = grad_y[b] * bt_act_deriv(d.act, y[b]);
+            bk = (d.buckets > 1) ? bucket[b] : 0;
+            if (gz_out && blockIdx.x == 0) gz_out[b] = gz;
+        }
         s_gz[t] = gz;
-        s_bk[t] = (d.buckets > 1) ? bucket[b] : 0;
-        if (gz_out && blockIdx.x == 0) gz_out[b] = gz;
+        s_bk[t] = bk;
     }
     __syncthreads();
+    // this sub-range: positions [p0, p1) of the workgroup's range
+    constexpr int PER = DBS_RANGE / DBS_SUB;
+    const int p0 = sub * PER, p1 = min(nb, p0 + PER);
     const float4 *x4 = reinterpret_cast<const float4 *>(x) + (size_t)b0 * in4 + c4;
-    float4 *gx4 = grad_x ? reinterpret_cast<float4 *>(grad_x) + (size_t)b0 * in4 + c4 : nullptr;
+    float4 *gx4 = (GX && grad_x) ? reinterpret_cast<float4 *>(grad_x) + (size_t)b0 * in4 + c4 : nullptr;
     constexpr int U = 8;
-    for (int t0 = 0; t0 < nb; t0 += U) {
-        float4 xv[U];
+    auto load = [&](int t0, float4(&xv)[U]) {
 #pragma unroll
-        for (int u = 0; u < U; u++)
-            xv[u] = (active && t0 + u < nb) ? x4[(size_t)(t0 + u) * in4] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int u = 0; u < U; u++) xv[u] = x4[(size_t)min(t0 + u, max(nb - 1, 0)) * in4];
+    };
+    auto consume = [&](int t0, const float4(&xv)[U]) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            if (t0 + u >= nb) break;
-            const int bk = s_bk[t0 + u];
-            const float gz = s_gz[t0 + u];
-            float4 gx = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const int bk = __builtin_amdgcn_readfirstlane(s_bk[min(t0 + u, DBS_RANGE - 1)]);
+            const float gz = (t0 + u < p1) ? s_gz[min(t0 + u, DBS_RANGE - 1)] : 0.0f;
 #pragma unroll
             for (int r = 0; r < ROWS; r++) {
-                const float m = (r == bk) ? gz : 0.0f;  // SelectPad: zeros outside the selected row
-                acc[r].x += m * xv[u].x, acc[r].y += m * xv[u].y, acc[r].z += m * xv[u].z, acc[r].w += m * xv[u].w;
-                gx.x += m * wr[r].x, gx.y += m * wr[r].y, gx.z += m * wr[r].z, gx.w += m * wr[r].w;
-                accb[r] += m;
+                if (r == bk) {  // scalar compare: one row executes
+                    acc[r].x += gz * xv[u].x, acc[r].y += gz * xv[u].y, acc[r].z += gz * xv[u].z, acc[r].w += gz * xv[u].w;
+                    accb[r] += gz;
+                    if constexpr (GX) {
+                        // 0 + gz*w, as the masked sum over rows gave
+                        if (gx4 && active && t0 + u < p1)
+                            gx4[(size_t)(t0 + u) * in4] = make_float4(0.0f + gz * wr[r].x, 0.0f + gz * wr[r].y,
+                                                                      0.0f + gz * wr[r].z, 0.0f + gz * wr[r].w);
+                    }
+                }
             }
-            if (gx4 && active) gx4[(size_t)(t0 + u) * in4] = gx;
+        }
+    };
+    if (p0 < p1) {
+        float4 xa[U], xb[U];
+        load(p0, xa);
+        for (int t0 = p0; t0 < p1; t0 += 2 * U) {
+            load(t0 + U, xb);
+            consume(t0, xa);
+            load(t0 + 2 * U, xa);
+            consume(t0 + U, xb);
         }
     }
-    if (active) {
+    // merge the sub-ranges in ascending order (sub 0 ends up with the workgroup's sums)
+    for (int rc = 0; rc < ROWS; rc += RCH) {
+        for (int sdone = 1; sdone < DBS_SUB; sdone++) {
+            __syncthreads();
+            if (sub == sdone) {
+#pragma unroll
+                for (int r = 0; r < RCH; r++)
+                    if (rc + r < ROWS) red[r][ct] = acc[rc + r];
+            }
+            __syncthreads();
+            if (sub == 0) {
+#pragma unroll
+                for (int r = 0; r < RCH; r++)
+                    if (rc + r < ROWS) {
+                        const float4 v = red[r][ct];
+                        acc[rc + r].x += v.x, acc[rc + r].y += v.y, acc[rc + r].z += v.z, acc[rc + r].w += v.w;
+                    }
+            }
+        }
+    }
+    if (ct == 0) {
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) redb[sub][r] = accb[r];
+    }
+    __syncthreads();
+    if (sub == 0 && active) {
         float *pw = part_w + (size_t)blockIdx.y * rows * d.in + (size_t)rows * (c4 * 4);
 #pragma unroll
         for (int r = 0; r < ROWS; r++)
@@ -367,7 +467,11 @@ __global__ __launch_bounds__(256) void dense_bwd_small(const float *__restrict__
     if (blockIdx.x == 0 && threadIdx.x == 0) {
 #pragma unroll
         for (int r = 0; r < ROWS; r++)
-            if (r < rows) part_b[(size_t)blockIdx.y * rows + r] = accb[r];
+            if (r < rows) {
+                float t = redb[0][r];
+                for (int s2 = 1; s2 < DBS_SUB; s2++) t += redb[s2][r];
+                part_b[(size_t)blockIdx.y * rows + r] = t;
+            }
     }
 }
 
@@ -420,10 +524,16 @@ int dense_bwd_small_launch(hipStream_t s, const bt_dense_desc *d, const float *w
                            const float *loss_partials, int n_loss_partials, float *loss_sum, float *part_w,
                            float *part_b, int nr) {
     const int rows = d->out * d->buckets;
-    dim3 grid(bt_div_up(d->in / 4, 256), nr), block(256);
+    dim3 grid(bt_div_up(d->in / 4, DBS_CT), nr), block(DBS_CT * DBS_SUB);
 #define DBS(R)                                                                                                   \
-    BT_LAUNCH(BTK_DENSE_BWD_SMALL, s, (dense_bwd_small<R>), grid, block, 0, w, x, bucket, y, grad_y, part_w, part_b, \
-              grad_x, *d, DBS_RANGE, gz_out, loss_partials, n_loss_partials, loss_sum)
+    do {                                                                                                         \
+        if (grad_x)                                                                                              \
+            BT_LAUNCH(BTK_DENSE_BWD_SMALL, s, (dense_bwd_small<R, true>), grid, block, 0, w, x, bucket, y, grad_y, \
+                      part_w, part_b, grad_x, *d, DBS_RANGE, gz_out, loss_partials, n_loss_partials, loss_sum);  \
+        else                                                                                                     \
+            BT_LAUNCH(BTK_DENSE_BWD_SMALL, s, (dense_bwd_small<R, false>), grid, block, 0, w, x, bucket, y, grad_y, \
+                      part_w, part_b, grad_x, *d, DBS_RANGE, gz_out, loss_partials, n_loss_partials, loss_sum);  \
+    } while (0)
     if (rows <= 1) DBS(1);
     else if (rows <= 2) DBS(2);
     else if (rows <= 4) DBS(4);
@@ -432,11 +542,8 @@ int dense_bwd_small_launch(hipStream_t s, const bt_dense_desc *d, const float *w
 #undef DBS
     BT_LAUNCH_CHECK();
     const size_t nw = (size_t)rows * d->in;
-    BT_LAUNCH(BTK_SUM_PARTIALS, s, sum_partials_kernel, dim3(bt_div_up(nw, 32)), dim3(256), 0, part_w, nr, nw, dw);
-    BT_LAUNCH_CHECK();
-    BT_LAUNCH(BTK_SUM_PARTIALS, s, sum_partials_kernel, dim3(bt_div_up(rows, 32)), dim3(256), 0, part_b, nr,
-              (size_t)rows, dbias);
-    BT_LAUNCH_CHECK();
+    if (int rc = sum_partials_launch(s, part_w, nr, nw, dw)) return rc;
+    if (int rc = sum_partials_launch(s, part_b, nr, (size_t)rows, dbias)) return rc;
     return BT_OK;
 }
 
@@ -534,12 +641,8 @@ int bt_dense_backward(void *stream, const bt_dense_desc *d, const float *w, cons
                        grad_y, part_w, part_b, *d);
     BT_LAUNCH_CHECK();
     const size_t nw = (size_t)rows * d->in;
-    BT_LAUNCH(BTK_SUM_PARTIALS, s, sum_partials_kernel, dim3(bt_div_up(nw, 32)), dim3(256), 0, part_w, nr, nw, dw);
-    BT_LAUNCH_CHECK();
-    BT_LAUNCH(BTK_SUM_PARTIALS, s, sum_partials_kernel, dim3(bt_div_up(rows, 32)), dim3(256), 0, part_b, nr, (size_t)rows,
-                       dbias);
-    BT_LAUNCH_CHECK();
-    return BT_OK;
+    if (int rc = sum_partials_launch(s, part_w, nr, nw, dw)) return rc;
+    return sum_partials_launch(s, part_b, nr, (size_t)rows, dbias);
 }
 
 int bt_sigmoid_mse(void *stream, int batch, const float *y, const float *targets, const float *entry_weights,

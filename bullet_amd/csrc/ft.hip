@@ -26,6 +26,9 @@ constexpr int FT_CHUNK = 256;  // positions per index chunk (local ids fit u16)
 
 // entries of one chunk's sorted list: every pair plus <= 3 padding ids per feature (runs are 4-aligned)
 __host__ __device__ inline int ft_sorted_cap(int nnz, int cols) { return (FT_CHUNK * nnz + 3 * cols + 7) & ~7; }
+// 4-pair blocks of a chunk's padded list (rounded so LDS arrays behind it stay 16-B aligned)
+__host__ __device__ inline int ft_blk_cap(int nnz, int cols) { return (ft_sorted_cap(nnz, cols) / 4 + 7) & ~7; }
+__host__ __device__ inline int ft_offl_words(int cols) { return (cols + 1 + 3) & ~3; }
 
 // tests: BT_FT_FORCE_GENERIC=1 runs the any-shape kernels on every shape
 bool force_generic() {
@@ -165,21 +168,39 @@ __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t 
     const int e_lo = wave * per_wave;
     const int e_hi = min(n_e, e_lo + per_wave);
 
-    // pass 1
-    for (int e = e_lo + sub; e - sub < e_hi; e += eps) {
-        int j = -1;
-        if (e < e_hi && li < nnz) j = idx[(size_t)e * nnz + li];
+    // The wave's index lists are read once, all loads in flight together (IDX_REG steps live in registers; longer
+    // sub-ranges -- few waves or very short lists -- reload the rest from L2 in pass 2).
+    constexpr int IDX_REG = 16;
+    const int nsteps = (per_wave + eps - 1) / eps;
+    int jr[IDX_REG];
+#pragma unroll
+    for (int st = 0; st < IDX_REG; st++) {
+        const int e = e_lo + st * eps + sub;
+        jr[st] = (st < nsteps && e < e_hi && li < nnz) ? idx[(size_t)e * nnz + li] : -1;
+    }
+    const unsigned long long seg = (slot == 64) ? ~0ull : (((1ull << slot) - 1) << (sub * slot));
+    // list length of this lane's entry: the first invalid index ends it (write.rs:231)
+    auto n_valid = [&](int e, int j) {
         const bool inval = (e < e_hi) && (li >= nnz || j < 0 || j >= cols);
-        // first invalid lane inside this entry's lane segment
-        unsigned long long bal = __ballot(inval);
-        unsigned long long seg = (slot == 64) ? ~0ull : (((1ull << slot) - 1) << (sub * slot));
-        unsigned long long m = bal & seg;
-        int nvalid = m ? (__ffsll((long long)m) - 1 - sub * slot) : slot;
+        const unsigned long long m = __ballot(inval) & seg;
+        return m ? (__ffsll((long long)m) - 1 - sub * slot) : slot;
+    };
+
+    // pass 1
+    auto count_step = [&](int e, int j) {
+        const int nvalid = n_valid(e, j);
         if (e < e_hi && li < nvalid) atomicAdd(&cnt[(size_t)wave * cols + j], 1u);
+    };
+#pragma unroll
+    for (int st = 0; st < IDX_REG; st++)
+        if (st < nsteps) count_step(e_lo + st * eps + sub, jr[st]);
+    for (int st = IDX_REG; st < nsteps; st++) {
+        const int e = e_lo + st * eps + sub;
+        count_step(e, (e < e_hi && li < nnz) ? idx[(size_t)e * nnz + li] : -1);
     }
     __syncthreads();
 
-    // scan: thread t owns features [t*per, (t+1)*per)
+    // scan: thread t owns features [t*per, (t+1)*per); block-wide exclusive scan of the padded totals
     {
         const int per = (cols + blockDim.x - 1) / blockDim.x;
         const int f_lo = min(cols, (int)threadIdx.x * per), f_hi = min(cols, f_lo + per);
@@ -189,18 +210,16 @@ __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t 
             for (int w2 = 0; w2 < nwaves; w2++) t += cnt[(size_t)w2 * cols + f];
             s += (t + 3) & ~3u;  // every feature's run is padded to a multiple of 4 entries
         }
-        tsum[threadIdx.x] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) {  // <= 256 values
-            uint32_t run = 0;
-            for (int i = 0; i < (int)blockDim.x; i++) {
-                uint32_t v = tsum[i];
-                tsum[i] = run;
-                run += v;
-            }
+        uint32_t incl = s;  // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
         }
+        if (lane == 63) tsum[wave] = incl;
         __syncthreads();
-        uint32_t run = tsum[threadIdx.x];
+        uint32_t run = incl - s;
+        for (int w2 = 0; w2 < wave; w2++) run += tsum[w2];
         for (int f = f_lo; f < f_hi; f++) {
             my_offs[f] = run;
             for (int w2 = 0; w2 < nwaves; w2++) {
@@ -217,14 +236,8 @@ __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t 
     // pass 2
     uint32_t *start = cnt + (size_t)wave * cols;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int e = e_lo + sub; e - sub < e_hi; e += eps) {
-        int j = -1;
-        if (e < e_hi && li < nnz) j = idx[(size_t)e * nnz + li];
-        const bool inval = (e < e_hi) && (li >= nnz || j < 0 || j >= cols);
-        unsigned long long bal = __ballot(inval);
-        unsigned long long seg = (slot == 64) ? ~0ull : (((1ull << slot) - 1) << (sub * slot));
-        unsigned long long m = bal & seg;
-        int nvalid = m ? (__ffsll((long long)m) - 1 - sub * slot) : slot;
+    auto place_step = [&](int e, int j) {
+        const int nvalid = n_valid(e, j);
         const bool active = (e < e_hi) && (li < nvalid);
         // lanes holding the same feature
         unsigned long long peers = __ballot(active);
@@ -239,6 +252,13 @@ __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t 
             my_sorted[base + rank] = (uint16_t)(e << 7);  // stored as the byte offset of the entry's 128-B tile row
             if (rank == count - 1) start[j] = base + count;
         }
+    };
+#pragma unroll
+    for (int st = 0; st < IDX_REG; st++)
+        if (st < nsteps) place_step(e_lo + st * eps + sub, jr[st]);
+    for (int st = IDX_REG; st < nsteps; st++) {
+        const int e = e_lo + st * eps + sub;
+        place_step(e, (e < e_hi && li < nnz) ? idx[(size_t)e * nnz + li] : -1);
     }
 }
 
@@ -560,8 +580,10 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
     float *acc = lds_f;                                   // [cols][32]
     float *gt = acc + (size_t)d.cols * LDS_RT;            // [FT_CHUNK + 1][32], last row = zeros (padding target)
     uint32_t *offl = reinterpret_cast<uint32_t *>(gt + (FT_CHUNK + 1) * LDS_RT);  // [cols + 1]
-    uint16_t *srt = reinterpret_cast<uint16_t *>(offl + ((d.cols + 1 + 1) & ~1));  // [ft_sorted_cap]
-    float *w1t = reinterpret_cast<float *>(srt + ft_sorted_cap(d.nnz, d.cols));     // FUSED: [n_inputs][w1_rows][TW]
+    uint16_t *srt = reinterpret_cast<uint16_t *>(offl + ft_offl_words(d.cols));  // [ft_sorted_cap]
+    uint16_t *blkf = srt + ft_sorted_cap(d.nnz, d.cols);                           // [ft_sorted_cap / 4] feature of each block
+    int *span = reinterpret_cast<int *>(blkf + ft_blk_cap(d.nnz, d.cols));         // [4] (2 used): widest run, in groups
+    float *w1t = reinterpret_cast<float *>(span + 4);                               // FUSED: [n_inputs][w1_rows][TW]
     const int rt = blockIdx.x % ntiles, cg = blockIdx.x / ntiles;
     const int half_rows = d.rows / 2;
     const int nchunks = d.n_inputs * chunks_per_input;
@@ -578,55 +600,63 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
     if (threadIdx.x < LDS_RT) gt[FT_CHUNK * LDS_RT + threadIdx.x] = 0.0f;
 
     const int s8 = threadIdx.x & 7, el0 = threadIdx.x >> 3;  // staging role: 128 entries x 8 float4 per pass
-    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;  // reduce role: 64 groups of 16 lanes (float2)
+    // reduce role: 128 groups of 8 lanes x float4, two whole rows per ds_read_b128 lane group (fwd_gather_slot)
+    int rg_e, rg_s;
+    fwd_gather_slot(threadIdx.x & 63, rg_e, rg_s);
+    const int grp = (threadIdx.x >> 6) * 8 + rg_e;
+    constexpr int NGRP = LDS_THREADS / 8;
+    if (threadIdx.x < 4) span[threadIdx.x] = 0;
     float4 bsum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int c_lo = cg * chunks_per_wg, c_hi = min(nchunks, c_lo + chunks_per_wg);
     // Staging registers: the NEXT chunk's global loads are issued before the current chunk's LDS reduction
     // and consumed after it, so HBM latency overlaps the reduction without a second LDS buffer.
     constexpr int NPASS = FT_CHUNK / 128;
     float4 r_go[NPASS], r_a[NPASS], r_b[NPASS];
-    uint32_t r_srt[10], r_off[2];
+    constexpr int NSRT = 3;  // uint4 rounds that cover the sorted list (host-checked)
+    lds_u4_t r_srt[NSRT];  // (clang vector type: an array of HIP's uint4 struct ends up in scratch)
+    uint32_t r_off[2], r_nblk = 0;
     const int srt_cap = ft_sorted_cap(d.nnz, d.cols);
-    const int srt_words = srt_cap / 2;  // <= 10 * LDS_THREADS (host-checked)
+    const int srt_vec = srt_cap / 8;  // uint4 = 8 offsets
+    // per-thread element offsets inside a chunk (32-bit; the chunk base is wave-uniform and lives in SGPRs)
+    const uint32_t t_out = (uint32_t)el0 * d.out_ld + (PAIR ? rt * 16 + (s8 & 3) * 4 : rt * LDS_RT + s8 * 4);
+    const uint32_t t_sav = (uint32_t)el0 * d.rows + rt * 16 + (s8 & 3) * 4;
     auto prefetch = [&](int c) {
         const int k = c / chunks_per_input, cb = c % chunks_per_input;
         const int b0 = cb * FT_CHUNK;
         const int n_e = min(FT_CHUNK, d.batch - b0);
+        const float *go_base = grad_out + (size_t)b0 * d.out_ld + (size_t)k * out_w;
+        const float *out_base = out + (size_t)b0 * d.out_ld + (size_t)k * out_w;
+        const float *sav_base = saved + ((size_t)k * d.batch + b0) * d.rows;
 #pragma unroll
         for (int pass = 0; pass < NPASS; pass++) {
             const int el = el0 + pass * 128;
             r_go[pass] = r_a[pass] = r_b[pass] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (el < n_e) {
-                const int b = b0 + el;
                 if constexpr (FUSED) {
-                    r_go[pass].x = fs.gz[b];
-                    r_go[pass].y = __int_as_float(fs.bucket ? fs.bucket[b] : 0);
+                    r_go[pass].x = fs.gz[b0 + el];
+                    r_go[pass].y = __int_as_float(fs.bucket ? fs.bucket[b0 + el] : 0);
+                } else {
+                    r_go[pass] = *reinterpret_cast<const float4 *>(go_base + t_out + (uint32_t)pass * 128 * d.out_ld);
                 }
                 if constexpr (PAIR) {
-                    const int col16 = rt * 16 + (s8 & 3) * 4;
-                    if constexpr (!FUSED)
-                        r_go[pass] = *reinterpret_cast<const float4 *>(grad_out + (size_t)b * d.out_ld + (size_t)k * out_w + col16);
-                    const float *sv = saved + ((size_t)k * d.batch + b) * d.rows;
-                    r_a[pass] = *reinterpret_cast<const float4 *>(sv + col16);
-                    r_b[pass] = *reinterpret_cast<const float4 *>(sv + half_rows + col16);
+                    const float *sv = sav_base + t_sav + (uint32_t)pass * 128 * d.rows;
+                    r_a[pass] = *reinterpret_cast<const float4 *>(sv);
+                    r_b[pass] = *reinterpret_cast<const float4 *>(sv + half_rows);
                 } else {
-                    const size_t o = (size_t)b * d.out_ld + (size_t)k * out_w + rt * LDS_RT + s8 * 4;
-                    if constexpr (!FUSED) r_go[pass] = *reinterpret_cast<const float4 *>(grad_out + o);
-                    r_a[pass] = *reinterpret_cast<const float4 *>(out + o);
+                    r_a[pass] = *reinterpret_cast<const float4 *>(out_base + t_out + (uint32_t)pass * 128 * d.out_ld);
                 }
             }
         }
         const uint32_t *go_ = offs + (size_t)c * (d.cols + 1);
+        // thread f keeps the bounds of feature f's run (r_off); features beyond 1024 take a second round below
+        r_off[0] = go_[min((int)threadIdx.x, d.cols)];
+        r_off[1] = go_[min((int)threadIdx.x + 1, d.cols)];
+        r_nblk = go_[d.cols] >> 2;
+        const lds_u4_t *gs = reinterpret_cast<const lds_u4_t *>(sorted + (size_t)c * srt_cap);
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < NSRT; i++) {
             const int q = threadIdx.x + i * LDS_THREADS;
-            r_off[i] = (q <= d.cols) ? go_[q] : 0u;
-        }
-        const uint32_t *gs = reinterpret_cast<const uint32_t *>(sorted + (size_t)c * srt_cap);
-#pragma unroll
-        for (int i = 0; i < 10; i++) {
-            const int q = threadIdx.x + i * LDS_THREADS;
-            r_srt[i] = (q < srt_words) ? gs[q] : 0u;
+            r_srt[i] = gs[min(q, srt_vec - 1)];
         }
     };
     if (c_lo < c_hi) prefetch(c_lo);
@@ -649,66 +679,122 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
                 }
                 float4 g;
                 if constexpr (PAIR) {
-                    const float4 c0 = r_a[pass], c1 = r_b[pass];
-                    if (s8 < 4) {
-                        g.x = (go.x * c1.x) * bt_act_deriv(d.act, c0.x), g.y = (go.y * c1.y) * bt_act_deriv(d.act, c0.y);
-                        g.z = (go.z * c1.z) * bt_act_deriv(d.act, c0.z), g.w = (go.w * c1.w) * bt_act_deriv(d.act, c0.w);
-                    } else {
-                        g.x = (go.x * c0.x) * bt_act_deriv(d.act, c1.x), g.y = (go.y * c0.y) * bt_act_deriv(d.act, c1.y);
-                        g.z = (go.z * c0.z) * bt_act_deriv(d.act, c1.z), g.w = (go.w * c0.w) * bt_act_deriv(d.act, c1.w);
-                    }
+                    // lanes s8 < 4 hold rows of the first half (factor c0, partner c1), the others the second half
+                    const float4 own = (s8 < 4) ? r_a[pass] : r_b[pass], oth = (s8 < 4) ? r_b[pass] : r_a[pass];
+                    const float4 dv = bt_act_deriv4(d.act, own);
+                    g = make_float4((go.x * oth.x) * dv.x, (go.y * oth.y) * dv.y, (go.z * oth.z) * dv.z,
+                                    (go.w * oth.w) * dv.w);
                 } else {
-                    const float4 ov = r_a[pass];
-                    g.x = go.x * bt_act_deriv(d.act, ov.x), g.y = go.y * bt_act_deriv(d.act, ov.y);
-                    g.z = go.z * bt_act_deriv(d.act, ov.z), g.w = go.w * bt_act_deriv(d.act, ov.w);
+                    const float4 dv = bt_act_deriv4(d.act, r_a[pass]);
+                    g = make_float4(go.x * dv.x, go.y * dv.y, go.z * dv.z, go.w * dv.w);
                 }
                 *reinterpret_cast<float4 *>(gt + el * LDS_RT + s8 * 4) = g;
                 bsum.x += g.x, bsum.y += g.y, bsum.z += g.z, bsum.w += g.w;
             }
         }
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int q = threadIdx.x + i * LDS_THREADS;
-            if (q <= d.cols) offl[q] = r_off[i];
-        }
-        {
-            uint32_t *ls = reinterpret_cast<uint32_t *>(srt);
-#pragma unroll
-            for (int i = 0; i < 10; i++) {
-                const int q = threadIdx.x + i * LDS_THREADS;
-                if (q < srt_words) ls[q] = r_srt[i];
+        // Work split: the sorted list is a sequence of 4-pair blocks, every block inside one feature's (padded)
+        // run. Group g sums blocks [g*q, (g+1)*q): equal work whatever the feature distribution looks like.
+        const int nblk = (int)r_nblk;
+        const int q = max(1, (nblk + NGRP - 1) / NGRP);
+        const float rcp_q = 1.0f / (float)q;  // block -> group by a float multiply (exact: both < 2^12)
+        int *cur_span = span + (c & 1);
+        for (int f = threadIdx.x, rnd = 0; f < d.cols; f += LDS_THREADS, rnd++) {
+            uint32_t o0 = r_off[0], o1 = r_off[1];
+            if (rnd > 0) o0 = offs[(size_t)c * (d.cols + 1) + f], o1 = offs[(size_t)c * (d.cols + 1) + f + 1];
+            offl[f] = o0;
+            const int sb = (int)(o0 >> 2), eb = (int)(o1 >> 2);
+            for (int i = sb; i < eb; i++) blkf[i] = (uint16_t)f;
+            if (eb > sb) {
+                const int width = (int)(((float)(eb - 1) + 0.5f) * rcp_q) - (int)(((float)sb + 0.5f) * rcp_q);
+                if (width > 0) atomicMax(cur_span, width);
             }
+        }
+#pragma unroll
+        for (int i = 0; i < NSRT; i++) {
+            const int qq = threadIdx.x + i * LDS_THREADS;
+            if (qq < srt_vec) reinterpret_cast<lds_u4_t *>(srt)[qq] = r_srt[i];
         }
         __syncthreads();
+        if (threadIdx.x == 0) span[(c + 1) & 1] = 0;  // next chunk's counter (its writers come after the next barrier)
         if (c + 1 < c_hi) prefetch(c + 1);
-        for (int f = grp; f < d.cols; f += LDS_THREADS / 16) {
-            const uint32_t s = offl[f], e = offl[f + 1];
-            if (s == e) continue;
-            float2 a = make_float2(0.0f, 0.0f);
-            const char *gb = reinterpret_cast<const char *>(gt);
-            const unsigned lane_off = sub * 8;
-            // runs are 4-aligned and padded with the zero-row offset: no per-element predicates. The list holds
-            // byte offsets (entry * 128) as u16 pairs, so an address is "packed half + lane offset" (one SDWA add);
-            // the next block's offsets are fetched while this block's rows are in flight.
-            uint2 w = *reinterpret_cast<const uint2 *>(srt + s);
-            for (uint32_t q = s; q < e; q += 4) {
-                const uint32_t qn = min(q + 4, e - 4);
-                const uint64_t wn64 = *(const volatile __attribute__((address_space(3))) uint64_t *)(srt + qn);  // volatile: stays in this iteration
-                const uint2 wn = make_uint2((uint32_t)wn64, (uint32_t)(wn64 >> 32));
-                const float2 v0 = *reinterpret_cast<const float2 *>(gb + ((w.x & 0xffffu) + lane_off));
-                const float2 v1 = *reinterpret_cast<const float2 *>(gb + ((w.x >> 16) + lane_off));
-                const float2 v2 = *reinterpret_cast<const float2 *>(gb + ((w.y & 0xffffu) + lane_off));
-                const float2 v3 = *reinterpret_cast<const float2 *>(gb + ((w.y >> 16) + lane_off));
-                a.x += v0.x, a.y += v0.y;
-                a.x += v1.x, a.y += v1.y;
-                a.x += v2.x, a.y += v2.y;
-                a.x += v3.x, a.y += v3.y;
-                w = wn;
+
+        const int b0 = grp * q, b1 = min(nblk, b0 + q);
+        // A run that began in an earlier group can only be the first one here: its sum is parked in h_part and
+        // added after the groups before it (rank = distance to the group that owns the run's start), so every
+        // feature row of `acc` has one writer at a time and a fixed order of additions.
+        float4 h_part = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        int h_f = 0, h_rank = 0;
+        {
+            const char *gb = reinterpret_cast<const char *>(gt) + rg_s * 16;
+            typedef const volatile __attribute__((address_space(3))) uint64_t *vids_t;
+            typedef const volatile __attribute__((address_space(3))) uint16_t *vblk_t;
+            constexpr uint32_t PAD2 = ((uint32_t)(FT_CHUNK << 7) << 16) | (uint32_t)(FT_CHUNK << 7);  // two zero-row offsets
+            const bool work = b0 < b1;
+            const int last = max(b1 - 1, 0);
+            uint2 w = make_uint2(PAD2, PAD2);
+            int f = 0, fcur = 0;
+            bool headrun = false;
+            if (work) {
+                w = *reinterpret_cast<const uint2 *>(srt + b0 * 4);
+                f = fcur = blkf[b0];
+                const int sb0 = (int)(offl[f] >> 2);
+                headrun = sb0 < b0;
+                if (headrun) h_rank = grp - (int)(((float)sb0 + 0.5f) * rcp_q), h_f = f;
             }
-            float2 *dst = reinterpret_cast<float2 *>(acc + f * LDS_RT + sub * 2);  // owned by this group only
-            float2 cur = *dst;
-            cur.x += a.x, cur.y += a.y;
-            *dst = cur;
+            float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            // q trips for every group (wave-uniform loop); groups past their range sum the zero row.
+            for (int i = 0; i < q; i++) {
+                // the next block's offsets / feature are fetched ahead of this block's rows (volatile keeps the
+                // loads in this iteration), and the running row of `acc` is read alongside the gathers, so a block
+                // costs one LDS round trip whether or not a run ends in it
+                const int bn = b0 + i + 1;
+                const bool nact = bn < b1;
+                const int bnc = min(bn, last);
+                const uint64_t wn64 = *(vids_t)(srt + bnc * 4);
+                const int fn_raw = *(vblk_t)(blkf + bnc);
+                const bool chg = f != fcur;
+                float4 *dst = reinterpret_cast<float4 *>(acc + fcur * LDS_RT + rg_s * 4);
+                typedef float lds_f4_t __attribute__((ext_vector_type(4)));
+                // volatile: read with the gathers, not inside the branch below (where it would cost a round trip)
+                const lds_f4_t old = *(const volatile __attribute__((address_space(3))) lds_f4_t *)dst;
+                const float4 v0 = *reinterpret_cast<const float4 *>(gb + (w.x & 0xffffu));
+                const float4 v1 = *reinterpret_cast<const float4 *>(gb + (w.x >> 16));
+                const float4 v2 = *reinterpret_cast<const float4 *>(gb + (w.y & 0xffffu));
+                const float4 v3 = *reinterpret_cast<const float4 *>(gb + (w.y >> 16));
+                if (chg) {
+                    if (headrun) {
+                        h_part = a;
+                        headrun = false;
+                    } else {
+                        *dst = make_float4(old.x + a.x, old.y + a.y, old.z + a.z, old.w + a.w);
+                    }
+                    a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    fcur = f;
+                }
+                add4(a, v0), add4(a, v1), add4(a, v2), add4(a, v3);
+                w = nact ? make_uint2((uint32_t)wn64, (uint32_t)(wn64 >> 32)) : make_uint2(PAD2, PAD2);
+                f = nact ? fn_raw : f;
+            }
+            if (work) {
+                if (headrun) {
+                    h_part = a;
+                } else {
+                    float4 *dst = reinterpret_cast<float4 *>(acc + fcur * LDS_RT + rg_s * 4);
+                    float4 cur = *dst;
+                    add4(cur, a);
+                    *dst = cur;
+                }
+            }
+        }
+        const int max_rank = *cur_span;  // written before the barrier above
+        for (int r = 1; r <= max_rank; r++) {
+            __syncthreads();
+            if (h_rank == r) {
+                float4 *dst = reinterpret_cast<float4 *>(acc + h_f * LDS_RT + rg_s * 4);
+                float4 cur = *dst;
+                add4(cur, h_part);
+                *dst = cur;
+            }
         }
     }
     __syncthreads();
@@ -789,7 +875,7 @@ int ft_plan(const bt_ft_desc *d, FtPlan *p) {
     p->chunks_per_input = bt_div_up(d->batch, FT_CHUNK);
     p->nchunks = p->chunks_per_input * d->n_inputs;
     // LDS budget for the index kernel: nwaves*cols + 64*nwaves words
-    int wv = 4;
+    int wv = 8;
     while (wv > 1 && ((size_t)wv * d->cols + 64 * wv) * 4 > 150 * 1024) wv >>= 1;
     BT_REQUIRE(((size_t)wv * d->cols + 64 * wv) * 4 <= 150 * 1024, "bt_ft_backward: cols=%d too large", d->cols);
     p->index_waves = wv;
@@ -809,9 +895,10 @@ int ft_plan(const bt_ft_desc *d, FtPlan *p) {
     p->lds_fwd_bytes = (size_t)(d->cols + 1) * LDS_RT * sizeof(float) +
                        (size_t)(LDS_THREADS / 64) * FWD_EPW * fwd_strip_words((d->nnz + 31) / 32) * sizeof(uint32_t);
     p->lds_bwd_bytes = ((size_t)d->cols * LDS_RT + (FT_CHUNK + 1) * LDS_RT) * sizeof(float) +
-                       (size_t)((d->cols + 2) & ~1) * sizeof(uint32_t) + (size_t)ft_sorted_cap(d->nnz, d->cols) * sizeof(uint16_t);
+                       (size_t)ft_offl_words(d->cols) * sizeof(uint32_t) + (size_t)ft_sorted_cap(d->nnz, d->cols) * sizeof(uint16_t) +
+                       (size_t)ft_blk_cap(d->nnz, d->cols) * sizeof(uint16_t) + 4 * sizeof(int);
     p->lds_path = (p->vec == 4) && (d->rows % LDS_RT == 0) && p->lds_bwd_bytes <= 160 * 1024 &&
-                  p->lds_fwd_bytes <= 160 * 1024 && ft_sorted_cap(d->nnz, d->cols) / 2 <= 10 * LDS_THREADS;
+                  p->lds_fwd_bytes <= 160 * 1024 && ft_sorted_cap(d->nnz, d->cols) / 8 <= 3 * LDS_THREADS;
     p->ntiles = d->rows / LDS_RT;
     p->G = 1, p->chunks_per_wg = p->nchunks;
     if (p->lds_path) {

@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libbullet_amd.so")
+# BT_LIB_PATH: developer override to time experimental builds of the same library (never a fallback)
+SO_PATH = os.environ.get("BT_LIB_PATH") or os.path.join(_HERE, "libbullet_amd.so")
 
 ACT = {"identity": 0, "relu": 1, "crelu": 2, "screlu": 3, "sqrrelu": 4}
 INPUT = {"chess768": 0, "chess_buckets": 1, "chess_buckets_mirrored": 2, "ataxx147": 3, "ataxx98": 4}
