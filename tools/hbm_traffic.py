@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""profiles/hbm_traffic.json from the two rocprofv3 --pmc passes collected by tools/collect_pmc.sh.
+
+FETCH_SIZE / WRITE_SIZE are in KB. On gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read
+(MI355X_MICROARCH.md, HBM / rocprofv3 section), so it is doubled; WRITE_SIZE is exact for 16-B stores."""
+import collections
+import csv
+import json
+import sys
+
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_hbm"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/hbm_traffic.json"
+KERNELS = ["ft_fwd_lds", "ft_index_kernel", "ft_bwd_lds", "ft_bwd_merge", "dense_fwd_small", "dense_bwd_small",
+           "sum_partials4_kernel", "adamw_kernel"]
+
+
+def avg(path, counter):
+    acc, n = collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        for k in KERNELS:
+            if k + "<" in r["Kernel_Name"] or k + "(" in r["Kernel_Name"]:
+                acc[k] += float(r["Counter_Value"])
+                n[k] += 1
+    return {k: acc[k] / n[k] for k in acc}
+
+
+f, w = avg(f"{src}/FETCH_SIZE.csv", "FETCH_SIZE"), avg(f"{src}/WRITE_SIZE.csv", "WRITE_SIZE")
+out = {"_comment": __doc__.strip().replace("\n", " ")}
+for k in KERNELS:
+    if k in f and k in w:
+        name = k.replace("sum_partials4_kernel", "sum_partials_kernel")
+        out[name] = {"FETCH_SIZE_KB": round(f[k], 1), "WRITE_SIZE_KB": round(w[k], 1),
+                     "hbm_bytes_per_launch": round((2 * f[k] + w[k]) * 1024, 1)}
+json.dump(out, open(dst, "w"), indent=1)
+print(json.dumps(out, indent=1))
