@@ -82,17 +82,19 @@ int bt_internal_ft_backward_fused(void *stream, const bt_ft_desc *d, const float
                                   const int32_t *bucket, int head_rows, const float *out, const float *saved, float *dw,
                                   float *dbias, void *workspace, size_t workspace_bytes);
 // dense head (out == 1) backward with optional extras: gz_out [B] receives grad_y * f'(y); when loss_partials is
-// given, block (0,0) also sums them in order into loss_sum[0]
+// given, block (0,0) also sums them in order into loss_sum[0]. light: the small-footprint kernel shape that can share
+// a CU with a resident FT-backward workgroup (only without grad_x / gz_out)
 int bt_internal_dense_backward_head(void *stream, const bt_dense_desc *d, const float *w, const float *x,
                                     const int32_t *bucket, const float *y, const float *grad_y, float *dw, float *dbias,
                                     float *grad_x, float *gz_out, const float *loss_partials, int n_loss_partials,
-                                    float *loss_sum, void *workspace, size_t workspace_bytes);
+                                    float *loss_sum, void *workspace, size_t workspace_bytes, bool light);
 bool bt_internal_dense_head_ok(const bt_dense_desc *d);
-// dense head forward fused with sigmoid-MSE: writes y, grad_y and per-workgroup loss partials
+// dense head forward fused with sigmoid-MSE: writes y, grad_y, per-workgroup loss partials and (optionally) gz_out =
+// grad_y * f'(y), the gradient w.r.t. the layer's pre-activation
 int bt_internal_dense_forward_loss(void *stream, const bt_dense_desc *d, const float *w, const float *bias,
                                    const float *x, const int32_t *bucket, const float *targets,
-                                   const float *entry_weights, float *y, float *grad_y, float *loss_partials,
-                                   int *n_loss_partials);
+                                   const float *entry_weights, float *y, float *grad_y, float *gz_out,
+                                   float *loss_partials, int *n_loss_partials);
 bool bt_internal_dense_forward_loss_ok(const bt_dense_desc *d);
 
 // ---- device-side activation helpers (semantics: dfo.rs:47-103, pointwise.rs:54-139) ----

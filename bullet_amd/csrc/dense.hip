@@ -167,7 +167,36 @@ __global__ __launch_bounds__(256) void sum_partials4_kernel(const float *__restr
     }
 }
 
-int sum_partials_launch(hipStream_t s, const float *part, int nparts, size_t n, float *out) {
+// LDS-free shape for launches that must fit next to a resident FT-backward workgroup: one thread sums one float4
+// column over all partials, in order
+__global__ __launch_bounds__(64) void sum_partials_seq4_kernel(const float *__restrict__ part, int nparts, size_t n4,
+                                                               float *__restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= n4) return;
+    const float4 *src = reinterpret_cast<const float4 *>(part) + t;
+    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    int p = 0;
+    for (; p + 8 <= nparts; p += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = src[(size_t)(p + u) * n4];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s.x += v[u].x, s.y += v[u].y, s.z += v[u].z, s.w += v[u].w;
+    }
+    for (; p < nparts; p++) {
+        const float4 v = src[(size_t)p * n4];
+        s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+    reinterpret_cast<float4 *>(out)[t] = s;
+}
+
+int sum_partials_launch(hipStream_t s, const float *part, int nparts, size_t n, float *out, bool light = false) {
+    if (light && n % 4 == 0 && ((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        BT_LAUNCH(BTK_SUM_PARTIALS, s, sum_partials_seq4_kernel, dim3(bt_div_up(n / 4, 64)), dim3(64), 0, part, nparts, n / 4,
+                  out);
+        BT_LAUNCH_CHECK();
+        return BT_OK;
+    }
     const bool v4 = n % 4 == 0 && ((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
     if (v4)
         BT_LAUNCH(BTK_SUM_PARTIALS, s, sum_partials4_kernel, dim3(bt_div_up(n / 4, 32)), dim3(256), 0, part, nparts, n / 4, out);
@@ -264,6 +293,7 @@ constexpr int DF_THREADS = 1024;
 struct LossArgs {
     const float *targets, *entry_weights;
     float *grad_y, *loss_partials;
+    float *gz_out;  // optional: gradient w.r.t. this layer's pre-activation (what the FT backward consumes)
 };
 
 template <int NX, bool LOSS>
@@ -313,7 +343,11 @@ __global__ __launch_bounds__(DF_THREADS) void dense_fwd_small(const float *__res
                 if (la.entry_weights) l = g * l;
                 loss_acc += l;
                 const float dd = g * diff + g * diff;
-                if (lane == 0) la.grad_y[b] = dd * (sg * (1.0f + (-1.0f * sg)));
+                const float gy = dd * (sg * (1.0f + (-1.0f * sg)));
+                if (lane == 0) {
+                    la.grad_y[b] = gy;
+                    if (la.gz_out) la.gz_out[b] = gy * bt_act_deriv(d.act, yv);  // same product as dense_bwd_small
+                }
             }
         }
     }
@@ -338,23 +372,23 @@ constexpr int DBS_RANGE = 128;  // positions per workgroup in dense_bwd_small
 // merged in order => deterministic. GX: also emit dX = gz * W[bucket] (skipped when the FT backward forms it itself).
 constexpr int DBS_CT = 256;  // column threads (float4 columns) per workgroup
 constexpr int DBS_SUB = 2;  // position sub-ranges of a workgroup (one per 256 threads), merged in order at the end
-template <int ROWS, bool GX>
-__global__ __launch_bounds__(DBS_CT * DBS_SUB) void dense_bwd_small(const float *__restrict__ w, const float *__restrict__ x,
-                                                                 const int32_t *__restrict__ bucket,
-                                                                 const float *__restrict__ y,
-                                                                 const float *__restrict__ grad_y,
-                                                                 float *__restrict__ part_w, float *__restrict__ part_b,
-                                                                 float *__restrict__ grad_x, bt_dense_desc d, int range,
-                                                                 float *__restrict__ gz_out,
-                                                                 const float *__restrict__ loss_partials,
-                                                                 int n_loss_partials, float *__restrict__ loss_sum) {
+// DBS_SUB sub-ranges / U loads per batch: the stand-alone shape. <1, 4>: the "light" shape (4 waves, <= 96 VGPRs,
+// < 1 KiB of LDS) that fits on a CU next to a resident ft_bwd_lds workgroup, see bt_net_forward_backward.
+template <int ROWS, bool GX, int SUBS, int U>
+__device__ __forceinline__ void dense_bwd_small_body(const float *__restrict__ w, const float *__restrict__ x,
+                                                     const int32_t *__restrict__ bucket, const float *__restrict__ y,
+                                                     const float *__restrict__ grad_y, float *__restrict__ part_w,
+                                                     float *__restrict__ part_b, float *__restrict__ grad_x,
+                                                     const bt_dense_desc &d, int range, float *__restrict__ gz_out,
+                                                     const float *__restrict__ loss_partials, int n_loss_partials,
+                                                     float *__restrict__ loss_sum) {
     const int rows = d.buckets;  // out == 1
     if (loss_partials && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         float t = 0.0f;  // fixed-order final sum of the forward kernel's loss partials
         for (int i = 0; i < n_loss_partials; i++) t += loss_partials[i];
         loss_sum[0] = t;
     }
-    const int ct = threadIdx.x % DBS_CT, sub = threadIdx.x / DBS_CT;
+    const int ct = threadIdx.x % DBS_CT, sub = (SUBS > 1) ? threadIdx.x / DBS_CT : 0;
     const int in4 = d.in >> 2;
     const int c4 = min((int)(blockIdx.x * DBS_CT + ct), in4 - 1);  // clamped: loads stay unconditional
     const bool active = (int)(blockIdx.x * DBS_CT + ct) < in4;
@@ -376,10 +410,10 @@ __global__ __launch_bounds__(DBS_CT * DBS_SUB) void dense_bwd_small(const float 
     const int nb = b1 - b0;
     // per-position scalars (gz, bucket) staged once in LDS: the position loop then has no dependent global loads
     __shared__ float s_gz[DBS_RANGE];
-    __shared__ int s_bk[DBS_RANGE];
+    __shared__ uint8_t s_bk[DBS_RANGE];  // dense_bwd_small_ok: buckets <= 16
     constexpr int RCH = 2048 / DBS_CT;  // rows merged per round (32 KiB of LDS)
-    __shared__ float4 red[RCH][DBS_CT];
-    __shared__ float redb[DBS_SUB][16];
+    __shared__ float4 red[SUBS > 1 ? RCH : 1][SUBS > 1 ? DBS_CT : 1];
+    __shared__ float redb[SUBS > 1 ? SUBS : 1][16];
     for (int t = threadIdx.x; t < DBS_RANGE; t += blockDim.x) {
         float gz = 0.0f;  // positions past the end contribute nothing
         int bk = 0;
@@ -390,15 +424,14 @@ __global__ __launch_bounds__(DBS_CT * DBS_SUB) void dense_bwd_small(const float 
             if (gz_out && blockIdx.x == 0) gz_out[b] = gz;
         }
         s_gz[t] = gz;
-        s_bk[t] = bk;
+        s_bk[t] = (uint8_t)bk;
     }
     __syncthreads();
     // this sub-range: positions [p0, p1) of the workgroup's range
-    constexpr int PER = DBS_RANGE / DBS_SUB;
+    constexpr int PER = DBS_RANGE / SUBS;
     const int p0 = sub * PER, p1 = min(nb, p0 + PER);
     const float4 *x4 = reinterpret_cast<const float4 *>(x) + (size_t)b0 * in4 + c4;
     float4 *gx4 = (GX && grad_x) ? reinterpret_cast<float4 *>(grad_x) + (size_t)b0 * in4 + c4 : nullptr;
-    constexpr int U = 8;
     auto load = [&](int t0, float4(&xv)[U]) {
 #pragma unroll
         for (int u = 0; u < U; u++) xv[u] = x4[(size_t)min(t0 + u, max(nb - 1, 0)) * in4];
@@ -406,7 +439,7 @@ __global__ __launch_bounds__(DBS_CT * DBS_SUB) void dense_bwd_small(const float 
     auto consume = [&](int t0, const float4(&xv)[U]) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int bk = __builtin_amdgcn_readfirstlane(s_bk[min(t0 + u, DBS_RANGE - 1)]);
+            const int bk = __builtin_amdgcn_readfirstlane((int)s_bk[min(t0 + u, DBS_RANGE - 1)]);
             const float gz = (t0 + u < p1) ? s_gz[min(t0 + u, DBS_RANGE - 1)] : 0.0f;
 #pragma unroll
             for (int r = 0; r < ROWS; r++) {
@@ -434,8 +467,8 @@ __global__ __launch_bounds__(DBS_CT * DBS_SUB) void dense_bwd_small(const float 
         }
     }
     // merge the sub-ranges in ascending order (sub 0 ends up with the workgroup's sums)
-    for (int rc = 0; rc < ROWS; rc += RCH) {
-        for (int sdone = 1; sdone < DBS_SUB; sdone++) {
+    for (int rc = 0; SUBS > 1 && rc < ROWS; rc += RCH) {
+        for (int sdone = 1; sdone < SUBS; sdone++) {
             __syncthreads();
             if (sub == sdone) {
 #pragma unroll
@@ -453,11 +486,13 @@ __global__ __launch_bounds__(DBS_CT * DBS_SUB) void dense_bwd_small(const float 
             }
         }
     }
-    if (ct == 0) {
+    if constexpr (SUBS > 1) {
+        if (ct == 0) {
 #pragma unroll
-        for (int r = 0; r < ROWS; r++) redb[sub][r] = accb[r];
+            for (int r = 0; r < ROWS; r++) redb[sub][r] = accb[r];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (sub == 0 && active) {
         float *pw = part_w + (size_t)blockIdx.y * rows * d.in + (size_t)rows * (c4 * 4);
 #pragma unroll
@@ -468,11 +503,38 @@ __global__ __launch_bounds__(DBS_CT * DBS_SUB) void dense_bwd_small(const float 
 #pragma unroll
         for (int r = 0; r < ROWS; r++)
             if (r < rows) {
-                float t = redb[0][r];
-                for (int s2 = 1; s2 < DBS_SUB; s2++) t += redb[s2][r];
+                float t = accb[r];
+                if constexpr (SUBS > 1) {
+                    t = redb[0][r];
+                    for (int s2 = 1; s2 < SUBS; s2++) t += redb[s2][r];
+                }
                 part_b[(size_t)blockIdx.y * rows + r] = t;
             }
     }
+}
+
+template <int ROWS, bool GX>
+__global__ __launch_bounds__(DBS_CT * DBS_SUB) void dense_bwd_small(const float *__restrict__ w, const float *__restrict__ x,
+                                                                    const int32_t *__restrict__ bucket,
+                                                                    const float *__restrict__ y,
+                                                                    const float *__restrict__ grad_y,
+                                                                    float *__restrict__ part_w, float *__restrict__ part_b,
+                                                                    float *__restrict__ grad_x, bt_dense_desc d, int range,
+                                                                    float *__restrict__ gz_out,
+                                                                    const float *__restrict__ loss_partials,
+                                                                    int n_loss_partials, float *__restrict__ loss_sum) {
+    dense_bwd_small_body<ROWS, GX, DBS_SUB, 8>(w, x, bucket, y, grad_y, part_w, part_b, grad_x, d, range, gz_out,
+                                               loss_partials, n_loss_partials, loss_sum);
+}
+
+template <int ROWS>
+__global__ __launch_bounds__(DBS_CT) __attribute__((amdgpu_waves_per_eu(5, 5))) void dense_bwd_small_light(
+    const float *__restrict__ w, const float *__restrict__ x, const int32_t *__restrict__ bucket,
+    const float *__restrict__ y, const float *__restrict__ grad_y, float *__restrict__ part_w,
+    float *__restrict__ part_b, bt_dense_desc d, int range, const float *__restrict__ loss_partials,
+    int n_loss_partials, float *__restrict__ loss_sum) {
+    dense_bwd_small_body<ROWS, false, 1, 4>(w, x, bucket, y, grad_y, part_w, part_b, nullptr, d, range, nullptr,
+                                            loss_partials, n_loss_partials, loss_sum);
 }
 
 
@@ -498,7 +560,7 @@ int dense_fwd_small_launch(hipStream_t s, const bt_dense_desc *d, const float *w
     const int ppw = bt_div_up(d->batch, nwg);
     nwg = bt_div_up(d->batch, ppw);
     if (n_partials) *n_partials = nwg;
-    const LossArgs none{nullptr, nullptr, nullptr, nullptr};
+    const LossArgs none{nullptr, nullptr, nullptr, nullptr, nullptr};
 #define DFS(NX)                                                                                                   \
     case NX:                                                                                                      \
         if (la) {                                                                                                 \
@@ -522,9 +584,23 @@ int dense_fwd_small_launch(hipStream_t s, const bt_dense_desc *d, const float *w
 int dense_bwd_small_launch(hipStream_t s, const bt_dense_desc *d, const float *w, const float *x, const int32_t *bucket,
                            const float *y, const float *grad_y, float *dw, float *dbias, float *grad_x, float *gz_out,
                            const float *loss_partials, int n_loss_partials, float *loss_sum, float *part_w,
-                           float *part_b, int nr) {
+                           float *part_b, int nr, bool light = false) {
     const int rows = d->out * d->buckets;
     dim3 grid(bt_div_up(d->in / 4, DBS_CT), nr), block(DBS_CT * DBS_SUB);
+    if (light && !grad_x && !gz_out && rows <= 8) {
+#define DBL(R)                                                                                                    \
+    BT_LAUNCH(BTK_DENSE_BWD_SMALL, s, (dense_bwd_small_light<R>), grid, dim3(DBS_CT), 0, w, x, bucket, y, grad_y, part_w, \
+              part_b, *d, DBS_RANGE, loss_partials, n_loss_partials, loss_sum)
+        if (rows <= 1) DBL(1);
+        else if (rows <= 2) DBL(2);
+        else if (rows <= 4) DBL(4);
+        else DBL(8);
+#undef DBL
+        BT_LAUNCH_CHECK();
+        const size_t nwl = (size_t)rows * d->in;
+        if (int rc = sum_partials_launch(s, part_w, nr, nwl, dw, true)) return rc;
+        return sum_partials_launch(s, part_b, nr, (size_t)rows, dbias, true);
+    }
 #define DBS(R)                                                                                                   \
     do {                                                                                                         \
         if (grad_x)                                                                                              \
@@ -564,7 +640,7 @@ bool bt_internal_dense_head_ok(const bt_dense_desc *d) { return dense_validate(d
 int bt_internal_dense_backward_head(void *stream, const bt_dense_desc *d, const float *w, const float *x,
                                     const int32_t *bucket, const float *y, const float *grad_y, float *dw, float *dbias,
                                     float *grad_x, float *gz_out, const float *loss_partials, int n_loss_partials,
-                                    float *loss_sum, void *workspace, size_t workspace_bytes) {
+                                    float *loss_sum, void *workspace, size_t workspace_bytes, bool light) {
     if (int rc = dense_validate(d, "bt_dense_backward")) return rc;
     BT_REQUIRE(dense_bwd_small_ok(d), "bt_dense_backward(head): shape not supported");
     BT_REQUIRE(w && x && y && grad_y && dw && dbias && workspace, "bt_dense_backward: null pointer");
@@ -575,7 +651,7 @@ int bt_internal_dense_backward_head(void *stream, const bt_dense_desc *d, const 
     float *part_b = reinterpret_cast<float *>(static_cast<char *>(workspace) +
                                               bt_align((size_t)nr * rows * d->in * sizeof(float)));
     return dense_bwd_small_launch(bt_stream(stream), d, w, x, bucket, y, grad_y, dw, dbias, grad_x, gz_out, loss_partials,
-                                  n_loss_partials, loss_sum, part_w, part_b, nr);
+                                  n_loss_partials, loss_sum, part_w, part_b, nr, light);
 }
 
 bool bt_internal_dense_forward_loss_ok(const bt_dense_desc *d) {
@@ -584,12 +660,12 @@ bool bt_internal_dense_forward_loss_ok(const bt_dense_desc *d) {
 
 int bt_internal_dense_forward_loss(void *stream, const bt_dense_desc *d, const float *w, const float *bias,
                                    const float *x, const int32_t *bucket, const float *targets,
-                                   const float *entry_weights, float *y, float *grad_y, float *loss_partials,
-                                   int *n_loss_partials) {
+                                   const float *entry_weights, float *y, float *grad_y, float *gz_out,
+                                   float *loss_partials, int *n_loss_partials) {
     if (int rc = dense_validate(d, "bt_dense_forward")) return rc;
     BT_REQUIRE(bt_internal_dense_forward_loss_ok(d), "bt_dense_forward(loss): shape not supported");
     BT_REQUIRE(w && bias && x && y && targets && grad_y && loss_partials, "bt_dense_forward(loss): null pointer");
-    const LossArgs la{targets, entry_weights, grad_y, loss_partials};
+    const LossArgs la{targets, entry_weights, grad_y, loss_partials, gz_out};
     return dense_fwd_small_launch(bt_stream(stream), d, w, bias, x, bucket, y, &la, n_loss_partials);
 }
 

@@ -28,7 +28,6 @@ constexpr int FT_CHUNK = 256;  // positions per index chunk (local ids fit u16)
 __host__ __device__ inline int ft_sorted_cap(int nnz, int cols) { return (FT_CHUNK * nnz + 3 * cols + 7) & ~7; }
 // 4-pair blocks of a chunk's padded list (rounded so LDS arrays behind it stay 16-B aligned)
 __host__ __device__ inline int ft_blk_cap(int nnz, int cols) { return (ft_sorted_cap(nnz, cols) / 4 + 7) & ~7; }
-__host__ __device__ inline int ft_offl_words(int cols) { return (cols + 1 + 3) & ~3; }
 
 // tests: BT_FT_FORCE_GENERIC=1 runs the any-shape kernels on every shape
 bool force_generic() {
@@ -579,11 +578,11 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
     extern __shared__ float lds_f[];
     float *acc = lds_f;                                   // [cols][32]
     float *gt = acc + (size_t)d.cols * LDS_RT;            // [FT_CHUNK + 1][32], last row = zeros (padding target)
-    uint32_t *offl = reinterpret_cast<uint32_t *>(gt + (FT_CHUNK + 1) * LDS_RT);  // [cols + 1]
-    uint16_t *srt = reinterpret_cast<uint16_t *>(offl + ft_offl_words(d.cols));  // [ft_sorted_cap]
-    uint16_t *blkf = srt + ft_sorted_cap(d.nnz, d.cols);                           // [ft_sorted_cap / 4] feature of each block
+    uint16_t *srt = reinterpret_cast<uint16_t *>(gt + (FT_CHUNK + 1) * LDS_RT);    // [ft_sorted_cap]
+    uint16_t *blkf = srt + ft_sorted_cap(d.nnz, d.cols);                           // [ft_blk_cap] feature of each block
     int *span = reinterpret_cast<int *>(blkf + ft_blk_cap(d.nnz, d.cols));         // [4] (2 used): widest run, in groups
-    float *w1t = reinterpret_cast<float *>(span + 4);                               // FUSED: [n_inputs][w1_rows][TW]
+    uint8_t *hrank = reinterpret_cast<uint8_t *>(span + 4);                        // [2][NGRP] rank of a group's head run
+    float *w1t = reinterpret_cast<float *>(hrank + 2 * (LDS_THREADS / 8));          // FUSED: [n_inputs][w1_rows][TW]
     const int rt = blockIdx.x % ntiles, cg = blockIdx.x / ntiles;
     const int half_rows = d.rows / 2;
     const int nchunks = d.n_inputs * chunks_per_input;
@@ -606,6 +605,7 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
     const int grp = (threadIdx.x >> 6) * 8 + rg_e;
     constexpr int NGRP = LDS_THREADS / 8;
     if (threadIdx.x < 4) span[threadIdx.x] = 0;
+    if (threadIdx.x < 2 * NGRP) hrank[threadIdx.x] = 0;
     float4 bsum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int c_lo = cg * chunks_per_wg, c_hi = min(nchunks, c_lo + chunks_per_wg);
     // Staging registers: the NEXT chunk's global loads are issued before the current chunk's LDS reduction
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
         const int cb = c % chunks_per_input;
         const int kc = c / chunks_per_input;
         const int n_e = min(FT_CHUNK, d.batch - cb * FT_CHUNK);
-        __syncthreads();  // previous chunk's readers are done with gt / srt / offl
+        __syncthreads();  // previous chunk's readers are done with gt / srt / blkf
 #pragma unroll
         for (int pass = 0; pass < NPASS; pass++) {
             const int el = el0 + pass * 128;
@@ -698,15 +698,17 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
         const int q = max(1, (nblk + NGRP - 1) / NGRP);
         const float rcp_q = 1.0f / (float)q;  // block -> group by a float multiply (exact: both < 2^12)
         int *cur_span = span + (c & 1);
+        uint8_t *cur_rank = hrank + (c & 1) * NGRP;
         for (int f = threadIdx.x, rnd = 0; f < d.cols; f += LDS_THREADS, rnd++) {
             uint32_t o0 = r_off[0], o1 = r_off[1];
             if (rnd > 0) o0 = offs[(size_t)c * (d.cols + 1) + f], o1 = offs[(size_t)c * (d.cols + 1) + f + 1];
-            offl[f] = o0;
             const int sb = (int)(o0 >> 2), eb = (int)(o1 >> 2);
             for (int i = sb; i < eb; i++) blkf[i] = (uint16_t)f;
             if (eb > sb) {
-                const int width = (int)(((float)(eb - 1) + 0.5f) * rcp_q) - (int)(((float)sb + 0.5f) * rcp_q);
-                if (width > 0) atomicMax(cur_span, width);
+                // groups g_first+1 .. g_last start inside this run: their first run is a "head" of rank g - g_first
+                const int g_first = (int)(((float)sb + 0.5f) * rcp_q), g_last = (int)(((float)(eb - 1) + 0.5f) * rcp_q);
+                if (g_last > g_first) atomicMax(cur_span, g_last - g_first);
+                for (int g = g_first + 1; g <= g_last; g++) cur_rank[g] = (uint8_t)(g - g_first);
             }
         }
 #pragma unroll
@@ -715,7 +717,8 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
             if (qq < srt_vec) reinterpret_cast<lds_u4_t *>(srt)[qq] = r_srt[i];
         }
         __syncthreads();
-        if (threadIdx.x == 0) span[(c + 1) & 1] = 0;  // next chunk's counter (its writers come after the next barrier)
+        if (threadIdx.x == 0) span[(c + 1) & 1] = 0;  // next chunk's counters (their writers come after the next barrier)
+        if (threadIdx.x < NGRP) hrank[((c + 1) & 1) * NGRP + threadIdx.x] = 0;
         if (c + 1 < c_hi) prefetch(c + 1);
 
         const int b0 = grp * q, b1 = min(nblk, b0 + q);
@@ -737,9 +740,9 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
             if (work) {
                 w = *reinterpret_cast<const uint2 *>(srt + b0 * 4);
                 f = fcur = blkf[b0];
-                const int sb0 = (int)(offl[f] >> 2);
-                headrun = sb0 < b0;
-                if (headrun) h_rank = grp - (int)(((float)sb0 + 0.5f) * rcp_q), h_f = f;
+                h_rank = cur_rank[grp];
+                headrun = h_rank > 0;
+                h_f = f;
             }
             float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             // q trips for every group (wave-uniform loop); groups past their range sum the zero row.
@@ -895,8 +898,8 @@ int ft_plan(const bt_ft_desc *d, FtPlan *p) {
     p->lds_fwd_bytes = (size_t)(d->cols + 1) * LDS_RT * sizeof(float) +
                        (size_t)(LDS_THREADS / 64) * FWD_EPW * fwd_strip_words((d->nnz + 31) / 32) * sizeof(uint32_t);
     p->lds_bwd_bytes = ((size_t)d->cols * LDS_RT + (FT_CHUNK + 1) * LDS_RT) * sizeof(float) +
-                       (size_t)ft_offl_words(d->cols) * sizeof(uint32_t) + (size_t)ft_sorted_cap(d->nnz, d->cols) * sizeof(uint16_t) +
-                       (size_t)ft_blk_cap(d->nnz, d->cols) * sizeof(uint16_t) + 4 * sizeof(int);
+                       (size_t)ft_sorted_cap(d->nnz, d->cols) * sizeof(uint16_t) +
+                       (size_t)ft_blk_cap(d->nnz, d->cols) * sizeof(uint16_t) + 4 * sizeof(int) + 2 * (LDS_THREADS / 8);
     p->lds_path = (p->vec == 4) && (d->rows % LDS_RT == 0) && p->lds_bwd_bytes <= 160 * 1024 &&
                   p->lds_fwd_bytes <= 160 * 1024 && ft_sorted_cap(d->nnz, d->cols) / 8 <= 3 * LDS_THREADS;
     p->ntiles = d->rows / LDS_RT;

@@ -27,7 +27,7 @@ struct bt_net {
     void *ft_ws = nullptr, *dense_ws = nullptr;
     // side stream: the FT sorted index (depends only on the batch indices) is built while the forward runs
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_index = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_index = nullptr, ev_fwd = nullptr, ev_head = nullptr;
     size_t ft_ws_bytes = 0, dense_ws_bytes = 0;
 };
 
@@ -85,7 +85,7 @@ int check_batch(const bt_net *net, const bt_batch *b, const char *who) {
     return BT_OK;
 }
 
-int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss) {
+int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bool want_gz0 = false) {
     bt_ft_desc f = ft_desc(n, b->batch);
     const int32_t *idx[2] = {b->stm, b->nstm};
     if (int rc = bt_ft_forward(s, &f, n->params + n->t_off[0], n->params + n->t_off[1], idx, n->hid, n->saved)) return rc;
@@ -96,8 +96,8 @@ int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss) {
             // final layer + sigmoid-MSE + its gradient in one kernel; the partials are summed by the head backward
             if (int rc = bt_internal_dense_forward_loss(
                     s, &q, n->params + n->t_off[2 + 2 * k], n->params + n->t_off[3 + 2 * k], x, b->buckets, b->targets,
-                    n->d.use_entry_weights ? b->entry_weights : nullptr, n->a[k], n->grad_y, n->loss_partials,
-                    &n->n_loss_partials))
+                    n->d.use_entry_weights ? b->entry_weights : nullptr, n->a[k], n->grad_y,
+                    (want_gz0 && k == 0) ? n->gz0 : nullptr, n->loss_partials, &n->n_loss_partials))
                 return rc;
         } else if (int rc = bt_dense_forward(s, &q, n->params + n->t_off[2 + 2 * k], n->params + n->t_off[3 + 2 * k], x,
                                              b->buckets, n->a[k]))
@@ -195,7 +195,9 @@ int bt_net_create(const bt_net_desc *desc, int max_batch, float *ext_params, flo
     if ((rc = bt_malloc(&n->dense_ws, n->dense_ws_bytes))) return fail(rc);
     if (hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&n->ev_index, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&n->ev_index, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&n->ev_fwd, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&n->ev_head, hipEventDisableTiming) != hipSuccess) {
         bt_set_error("bt_net_create: could not create the side stream / events");
         return fail(BT_ERR_HIP);
     }
@@ -213,6 +215,8 @@ int bt_net_destroy(bt_net *n) {
     bt_free(n->ft_ws), bt_free(n->dense_ws);
     if (n->ev_fork) (void)hipEventDestroy(n->ev_fork);
     if (n->ev_index) (void)hipEventDestroy(n->ev_index);
+    if (n->ev_fwd) (void)hipEventDestroy(n->ev_fwd);
+    if (n->ev_head) (void)hipEventDestroy(n->ev_head);
     if (n->side) (void)hipStreamDestroy(n->side);
     delete n;
     return BT_OK;
@@ -260,11 +264,33 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
     bt_dense_desc q_last = dn_desc(n, L - 1, b->batch), q0 = dn_desc(n, 0, b->batch);
     const bool fuse_loss = bt_internal_dense_forward_loss_ok(&q_last) && bt_internal_dense_head_ok(&q_last);
     const bool fuse_ft = bt_internal_dense_head_ok(&q0) && bt_internal_ft_fused_ok(&f, q0.buckets);
-    if (int rc = forward_impl(n, s, b, fuse_loss)) return rc;
+    // Single-layer head with both fusions: the forward already produced gz (all the FT backward needs), so the
+    // head's own backward (dW1, db1, final loss sum) runs on the side stream NEXT TO the FT backward -- one is
+    // HBM-bound in a small-footprint kernel shape, the other LDS-bound, and they share the CUs.
+    const bool side_head = fuse_loss && fuse_ft && L == 1;
+    if (int rc = forward_impl(n, s, b, fuse_loss, side_head)) return rc;
     if (!fuse_loss)
         if (int rc = bt_sigmoid_mse(s, b->batch, n->a[L - 1], b->targets,
                                     n->d.use_entry_weights ? b->entry_weights : nullptr, loss_sum_dev, n->grad_y))
             return rc;
+    if (side_head) {
+        BT_HIP(hipEventRecord(n->ev_fwd, s));
+        BT_HIP(hipStreamWaitEvent(n->side, n->ev_fwd, 0));  // side: after the index build (stream order) and the forward
+        if (int rc = bt_internal_dense_backward_head(n->side, &q0, n->params + n->t_off[2], n->hid, b->buckets, n->a[0],
+                                                     n->grad_y, n->grads + n->t_off[2], n->grads + n->t_off[3], nullptr,
+                                                     nullptr, n->loss_partials, n->n_loss_partials, loss_sum_dev,
+                                                     n->dense_ws, n->dense_ws_bytes, true))
+            return rc;
+        BT_HIP(hipEventRecord(n->ev_head, n->side));
+        BT_HIP(hipStreamWaitEvent(s, n->ev_index, 0));  // main: join the index build
+        if (int rc = bt_internal_ft_backward_fused(s, &f, n->gz0, n->params + n->t_off[2],
+                                                   n->d.dense_bucketed[0] ? b->buckets : nullptr, q0.buckets, n->hid,
+                                                   n->saved, n->grads + n->t_off[0], n->grads + n->t_off[1], n->ft_ws,
+                                                   n->ft_ws_bytes))
+            return rc;
+        BT_HIP(hipStreamWaitEvent(s, n->ev_head, 0));  // the step's gradients and loss are complete on `s`
+        return BT_OK;
+    }
     for (int k = L - 1; k >= 0; k--) {
         bt_dense_desc q = dn_desc(n, k, b->batch);
         const float *x = (k == 0) ? n->hid : n->a[k - 1];
@@ -278,7 +304,7 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
             if (int rc = bt_internal_dense_backward_head(s, &q, wk, x, b->buckets, n->a[k], gy, dwk, dbk,
                                                          ft_here ? nullptr : gx, ft_here ? n->gz0 : nullptr,
                                                          loss_here ? n->loss_partials : nullptr, n->n_loss_partials,
-                                                         loss_sum_dev, n->dense_ws, n->dense_ws_bytes))
+                                                         loss_sum_dev, n->dense_ws, n->dense_ws_bytes, false))
                 return rc;
         } else if (int rc = bt_dense_backward(s, &q, wk, x, b->buckets, n->a[k], gy, dwk, dbk, gx, n->dense_ws,
                                               n->dense_ws_bytes))

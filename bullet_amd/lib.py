@@ -236,8 +236,12 @@ class Net:
         self.n_flat = self.L.bt_net_param_count(C.byref(desc))
         # flat params / grads live in torch tensors so a harness can all-reduce / copy them
         self.params = torch.zeros(self.n_flat, dtype=torch.float32, device=device)
-        self.grads = torch.zeros(self.n_flat, dtype=torch.float32, device=device)
-        self.loss = torch.zeros(1, dtype=torch.float32, device=device)
+        # gradient and loss sum share one allocation (n_flat is a multiple of 4 floats), so data-parallel
+        # training all-reduces `step_buffer` once per step
+        self._gbuf = torch.zeros(self.n_flat + 4, dtype=torch.float32, device=device)
+        self.grads = self._gbuf[:self.n_flat]
+        self.loss = self._gbuf[self.n_flat:self.n_flat + 1]
+        self.step_buffer = self._gbuf[:self.n_flat + 1]
         h = C.c_void_p()
         check(self.L.bt_net_create(C.byref(desc), max_batch, self.params.data_ptr(), self.grads.data_ptr(),
                                    C.byref(h)))

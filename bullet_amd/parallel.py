@@ -19,13 +19,13 @@ def shard_range(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def allreduce_step_buffers(dist, flat_grads, loss_sum):
-    """Sum the flat gradient and the loss over ranks (in place). One collective for the whole model:
-    config 2 is a single 3.2 MB message; per-link bound ring over xGMI."""
+def allreduce_step_buffers(dist, step_buffer):
+    """Sum the step buffer over ranks (in place). The step buffer is the flat gradient with the loss sum stored
+    right behind it (`Net.step_buffer`), so a training step needs ONE collective: config 2 is a single 3.2 MB
+    message; a second 4-byte all-reduce would cost a full ring latency for nothing."""
     if dist is None:
         return
-    dist.all_reduce(flat_grads)
-    dist.all_reduce(loss_sum)
+    dist.all_reduce(step_buffer)
 
 
 def adj_factor(global_batch):

@@ -55,9 +55,9 @@ def _train(rank, world, use_dist):
     for _ in range(STEPS):
         loss, grads, _ = ob.net_fwd_bwd(d, params, stm[lo:hi].copy(), ntm[lo:hi].copy(), bk[lo:hi].copy(),
                                         tg[lo:hi].copy(), w[lo:hi].copy())
-        flat = torch.from_numpy(_flat(grads))
-        lsum = torch.tensor([loss], dtype=torch.float32)
-        parallel.allreduce_step_buffers(dist if use_dist else None, flat, lsum)
+        buf = torch.from_numpy(np.concatenate([_flat(grads), np.array([loss], np.float32)]))  # Net.step_buffer layout
+        parallel.allreduce_step_buffers(dist if use_dist else None, buf)
+        flat, lsum = buf[:-1], buf[-1:]
         grads = _unflat(flat.numpy(), grads)
         for p_, m_, v_, g_ in zip(params, m, v, grads):
             ob.adamw(p_, m_, v_, g_, parallel.adj_factor(N_POS), 1e-3)
