@@ -78,6 +78,18 @@ struct BtProfScope {
 
 // ---- internal cross-file entry points (not in the public header)
 bool bt_internal_ft_fused_ok(const bt_ft_desc *d, int head_rows);
+// FT forward that applies a one-output dense head to each tile while it is in registers: zpart receives
+// bt_internal_ft_head_parts(d) partial dot products per position ([part][batch]), summed by bt_internal_head_finish
+bool bt_internal_ft_forward_head_ok(const bt_ft_desc *d, int head_rows);
+int bt_internal_ft_head_parts(const bt_ft_desc *d);
+int bt_internal_ft_forward_head(void *stream, const bt_ft_desc *d, const float *w, const float *bias,
+                                const int32_t *const *idx, float *out, float *saved, const float *w1,
+                                const int32_t *bucket, int head_rows, float *zpart);
+// y = f(sum of the partials in order + bias[bucket]); sigmoid-MSE, its gradient, gz and loss partials like
+// bt_internal_dense_forward_loss
+int bt_internal_head_finish(void *stream, const bt_dense_desc *d, const float *zpart, int nparts, const float *bias,
+                            const int32_t *bucket, const float *targets, const float *entry_weights, float *y,
+                            float *grad_y, float *gz_out, float *loss_partials, int *n_loss_partials);
 int bt_internal_ft_backward_fused(void *stream, const bt_ft_desc *d, const float *gz, const float *w1,
                                   const int32_t *bucket, int head_rows, const float *out, const float *saved, float *dw,
                                   float *dbias, void *workspace, size_t workspace_bytes);

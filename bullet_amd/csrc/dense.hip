@@ -362,6 +362,49 @@ __global__ __launch_bounds__(DF_THREADS) void dense_fwd_small(const float *__res
     }
 }
 
+// Finishing pass of the head forward that ft_fwd_lds<HEAD> started: z[b] = sum of the per-tile partial dot products
+// (ascending part order) + bias[bucket]; then exactly the epilogue of dense_fwd_small<LOSS>.
+constexpr int HF_THREADS = 64;  // one wave per workgroup: many small workgroups, the partial loads are the latency
+__global__ __launch_bounds__(HF_THREADS) void head_finish_kernel(const float *__restrict__ zpart, int nparts,
+                                                                 const float *__restrict__ bias,
+                                                                 const int32_t *__restrict__ bucket,
+                                                                 float *__restrict__ y, bt_dense_desc d, LossArgs la) {
+    __shared__ float red[HF_THREADS];
+    const int b = blockIdx.x * HF_THREADS + threadIdx.x;
+    float l = 0.0f;
+    if (b < d.batch) {
+        float z = 0.0f;
+        int p = 0;
+        for (; p + 16 <= nparts; p += 16) {  // 16 loads in flight, added in ascending order
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = zpart[(size_t)(p + u) * d.batch + b];
+#pragma unroll
+            for (int u = 0; u < 16; u++) z += v[u];
+        }
+        for (; p < nparts; p++) z += zpart[(size_t)p * d.batch + b];
+        const int base = (d.buckets > 1) ? bucket[b] : 0;
+        const float yv = bt_act_fwd(d.act, z + bias[base]);
+        y[b] = yv;
+        const float sg = 1.0f / (1.0f + expf(-1.0f * yv));
+        const float diff = sg + (-1.0f * la.targets[b]);
+        const float g = la.entry_weights ? la.entry_weights[b] : 1.0f;
+        l = diff * diff;
+        if (la.entry_weights) l = g * l;
+        const float dd = g * diff + g * diff;
+        const float gy = dd * (sg * (1.0f + (-1.0f * sg)));
+        la.grad_y[b] = gy;
+        if (la.gz_out) la.gz_out[b] = gy * bt_act_deriv(d.act, yv);
+    }
+    red[threadIdx.x] = l;
+    __syncthreads();
+    for (int o = HF_THREADS >> 1; o > 0; o >>= 1) {  // fixed tree => deterministic partial
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) la.loss_partials[blockIdx.x] = red[0];
+}
+
 constexpr int DBS_RANGE = 128;  // positions per workgroup in dense_bwd_small
 
 // Backward for out == 1 heads (one selected row per position): every thread owns 4 input columns and keeps
@@ -667,6 +710,23 @@ int bt_internal_dense_forward_loss(void *stream, const bt_dense_desc *d, const f
     BT_REQUIRE(w && bias && x && y && targets && grad_y && loss_partials, "bt_dense_forward(loss): null pointer");
     const LossArgs la{targets, entry_weights, grad_y, loss_partials, gz_out};
     return dense_fwd_small_launch(bt_stream(stream), d, w, bias, x, bucket, y, &la, n_loss_partials);
+}
+
+int bt_internal_head_finish(void *stream, const bt_dense_desc *d, const float *zpart, int nparts, const float *bias,
+                            const int32_t *bucket, const float *targets, const float *entry_weights, float *y,
+                            float *grad_y, float *gz_out, float *loss_partials, int *n_loss_partials) {
+    if (int rc = dense_validate(d, "bt_dense_forward")) return rc;
+    BT_REQUIRE(d->out == 1 && zpart && bias && targets && y && grad_y && loss_partials && n_loss_partials,
+               "bt_dense_forward(head finish): bad arguments");
+    BT_REQUIRE(d->buckets == 1 || bucket, "bt_dense_forward: bucketed layer needs bucket indices");
+    const int nwg = bt_div_up(d->batch, HF_THREADS);
+    BT_REQUIRE(nwg <= 1024, "bt_dense_forward(head finish): batch too large for the loss-partial buffer");
+    const LossArgs la{targets, entry_weights, grad_y, loss_partials, gz_out};
+    BT_LAUNCH(BTK_DENSE_FWD_SMALL, bt_stream(stream), head_finish_kernel, dim3(nwg), dim3(HF_THREADS), 0, zpart, nparts,
+              bias, bucket, y, *d, la);
+    BT_LAUNCH_CHECK();
+    *n_loss_partials = nwg;
+    return BT_OK;
 }
 
 extern "C" {

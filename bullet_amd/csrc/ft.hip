@@ -409,14 +409,32 @@ __device__ __forceinline__ int fwd_gather_lane(int entry, int slot) {
 }
 __host__ __device__ constexpr int fwd_strip_words(int nround) { return nround * 32 + 4; }  // +4: bank skew
 
-template <bool PAIR, bool ALIGNED4, int NROUND>
+// HEAD: a one-output dense head (Matmul + Select of one row per position, matmul.rs:62-93, select.rs:12-26) is
+// applied to the tile while it is still in registers: every (perspective, row tile) leaves one partial dot
+// product per position in zpart[(k*ntiles + rt)][b]; a small finishing kernel adds them up in order. The
+// [B][2H] activations are still written (both backward passes read them) but not read back by a head forward.
+struct FtHeadSink {
+    const float *w1;        // head weights, column-major [w1_rows][n_inputs*out_w]
+    const int32_t *bucket;  // [B] or null
+    int w1_rows;            // = number of output buckets (one output each)
+    float *zpart;           // [n_inputs * ntiles][batch]
+};
+
+__device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lanes of an aligned quad, on every lane
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+    return v;
+}
+
+template <bool PAIR, bool ALIGNED4, int NROUND, bool HEAD>
 __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restrict__ w, const float *__restrict__ bias,
                                                           const int32_t *__restrict__ idx0,
                                                           const int32_t *__restrict__ idx1, float *__restrict__ out,
                                                           float *__restrict__ saved, bt_ft_desc d, int ntiles,
-                                                          int entries_per_wg) {
+                                                          int entries_per_wg, FtHeadSink hs) {
     extern __shared__ float wl[];  // [(cols + 1)][32]; row `cols` is all zero (target of masked slots)
     constexpr int SS = fwd_strip_words(NROUND);
+    constexpr int TW = PAIR ? 16 : 32;  // output columns per perspective covered by this row tile
     const int rt = blockIdx.x % ntiles, grp = blockIdx.x / ntiles;
     const int half_rows = d.rows / 2;
     for (int q = threadIdx.x; q < d.cols * 8; q += LDS_THREADS) {
@@ -426,6 +444,14 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
         *reinterpret_cast<float4 *>(wl + f * LDS_RT + s8 * 4) = v;
     }
     if (threadIdx.x < LDS_RT) wl[d.cols * LDS_RT + threadIdx.x] = 0.0f;
+    float *w1t = wl + (d.cols + 1) * LDS_RT + (LDS_THREADS / 64) * FWD_EPW * SS;  // HEAD: [n_inputs][w1_rows][TW]
+    if constexpr (HEAD) {
+        const int ow = PAIR ? half_rows : d.rows;
+        for (int q = threadIdx.x; q < d.n_inputs * hs.w1_rows * TW; q += LDS_THREADS) {
+            const int c = q % TW, bk = (q / TW) % hs.w1_rows, k = q / (TW * hs.w1_rows);
+            w1t[q] = hs.w1[(size_t)(k * ow + rt * TW + c) * hs.w1_rows + bk];
+        }
+    }
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -467,9 +493,18 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
             }
         }
     };
+    // HEAD: the bucket of this lane's gather-map entry, fetched one pass ahead like the indices
+    auto load_bucket = [&](int eb2) {
+        if (!HEAD || !hs.bucket) return 0;
+        const int e2 = min(eb2 + ge, E - 1);
+        return (int)hs.bucket[e2 - ((e2 >= d.batch) ? d.batch : 0)];
+    };
     int nxt[NROUND][4];
     load_idx(e_begin + wave * FWD_EPW, nxt);
+    int nxt_bk = load_bucket(e_begin + wave * FWD_EPW);
     for (int eb = e_begin + wave * FWD_EPW; eb < e_end; eb += PASS) {
+        const int bk = nxt_bk;
+        nxt_bk = load_bucket(eb + PASS);
         int reg[NROUND][4];
 #pragma unroll
         for (int q = 0; q < NROUND; q++)
@@ -543,14 +578,28 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
             const int partner = fwd_gather_lane(ge, gs ^ 4);
             const float4 o = make_float4(__shfl(c.x, partner), __shfl(c.y, partner), __shfl(c.z, partner),
                                          __shfl(c.w, partner));
+            const float4 pr = make_float4(c.x * o.x, c.y * o.y, c.z * o.z, c.w * o.w);
             if (live) {
                 *reinterpret_cast<float4 *>(saved + (size_t)e * d.rows + row) = c;
-                if (gs < 4)
-                    *reinterpret_cast<float4 *>(out + (size_t)b * d.out_ld + (size_t)k * out_w + rt * 16 + gs * 4) =
-                        make_float4(c.x * o.x, c.y * o.y, c.z * o.z, c.w * o.w);
+                if (gs < 4) *reinterpret_cast<float4 *>(out + (size_t)b * d.out_ld + (size_t)k * out_w + rt * 16 + gs * 4) = pr;
+            }
+            if constexpr (HEAD) {  // the 16 products live on the quad gs < 4
+                const float4 wv = *reinterpret_cast<const float4 *>(w1t + (k * hs.w1_rows + bk) * TW + (gs & 3) * 4);
+                float p = 0.0f;
+                p += pr.x * wv.x, p += pr.y * wv.y, p += pr.z * wv.z, p += pr.w * wv.w;
+                p = quad_sum(p);
+                if (live && gs == 0) hs.zpart[(size_t)(k * ntiles + rt) * d.batch + b] = p;
             }
         } else {
             if (live) *reinterpret_cast<float4 *>(out + (size_t)b * d.out_ld + (size_t)k * out_w + row) = c;
+            if constexpr (HEAD) {
+                const float4 wv = *reinterpret_cast<const float4 *>(w1t + (k * hs.w1_rows + bk) * TW + gs * 4);
+                float p = 0.0f;
+                p += c.x * wv.x, p += c.y * wv.y, p += c.z * wv.z, p += c.w * wv.w;
+                p = quad_sum(p);  // columns 0-15 on the quad gs < 4, 16-31 on the other
+                const float hi = __shfl(p, fwd_gather_lane(ge, gs ^ 4));
+                if (live && gs == 0) hs.zpart[(size_t)(k * ntiles + rt) * d.batch + b] = p + hi;
+            }
         }
     }
 }
@@ -981,7 +1030,81 @@ int bt_internal_ft_backward_fused(void *stream, const bt_ft_desc *d, const float
 }
 
 namespace {
+
+size_t ft_head_lds_bytes(const bt_ft_desc *d, int head_rows) {
+    return (size_t)d->n_inputs * head_rows * (d->pairwise ? 16 : 32) * sizeof(float);
+}
+
+int ft_forward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, const float *w, const float *bias,
+                          const int32_t *i0, const int32_t *i1, float *out, float *saved, const FtHeadSink *head) {
+    const long long E = (long long)d->n_inputs * d->batch;
+    int G = 256 / p.ntiles;
+    if (G < 1) G = 1;
+    long long epw = (E + G - 1) / G;
+    epw = (epw + 127) / 128 * 128;  // whole passes of 16 waves x 8 entries
+    G = (int)((E + epw - 1) / epw);
+    const int nround = (d->nnz + 31) / 32;
+    const bool al4 = d->nnz % 4 == 0 && (reinterpret_cast<uintptr_t>(i0) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(i1) & 15) == 0;
+    dim3 lgrid(p.ntiles * G), lblock(LDS_THREADS);
+    const FtHeadSink hs = head ? *head : FtHeadSink{nullptr, nullptr, 0, nullptr};
+    const size_t lds = p.lds_fwd_bytes + (head ? ft_head_lds_bytes(d, hs.w1_rows) : 0);
+#define FWD_LDS(PAIR, AL4, NROUND, HEAD)                                                                           \
+    do {                                                                                                           \
+        if (int rc = set_lds(ft_fwd_lds<PAIR, AL4, NROUND, HEAD>, lds)) return rc;                                 \
+        BT_LAUNCH(BTK_FT_FWD_LDS, s, (ft_fwd_lds<PAIR, AL4, NROUND, HEAD>), lgrid, lblock, lds, w, bias, i0, i1, out, \
+                  saved, *d, p.ntiles, (int)epw, hs);                                                              \
+    } while (0)
+#define FWD_LDS3(PAIR, AL4, NROUND)                                                                                \
+    do {                                                                                                           \
+        if (head) FWD_LDS(PAIR, AL4, NROUND, true);                                                                \
+        else FWD_LDS(PAIR, AL4, NROUND, false);                                                                    \
+    } while (0)
+#define FWD_LDS2(PAIR, AL4)                                                                                        \
+    do {                                                                                                           \
+        if (nround == 1) FWD_LDS3(PAIR, AL4, 1);                                                                   \
+        else FWD_LDS3(PAIR, AL4, 2);                                                                               \
+    } while (0)
+    if (d->pairwise) {
+        if (al4) FWD_LDS2(true, true);
+        else FWD_LDS2(true, false);
+    } else {
+        if (al4) FWD_LDS2(false, true);
+        else FWD_LDS2(false, false);
+    }
+#undef FWD_LDS2
+#undef FWD_LDS3
+#undef FWD_LDS
+    BT_LAUNCH_CHECK();
+    return BT_OK;
+}
+
 }  // namespace
+
+// ---- internal: FT forward that also leaves the partial dot products of a one-output dense head (net.hip)
+bool bt_internal_ft_forward_head_ok(const bt_ft_desc *d, int head_rows) {
+    FtPlan p;
+    if (ft_validate(d, "ft_forward_head_ok") || ft_plan(d, &p)) return false;
+    return p.lds_path && !force_generic() && head_rows >= 1 && head_rows <= FtPlan::kFusedMaxRows &&
+           p.lds_fwd_bytes + ft_head_lds_bytes(d, head_rows) <= 160 * 1024;
+}
+
+int bt_internal_ft_head_parts(const bt_ft_desc *d) { return d->n_inputs * (d->rows / LDS_RT); }
+
+int bt_internal_ft_forward_head(void *stream, const bt_ft_desc *d, const float *w, const float *bias,
+                                const int32_t *const *idx, float *out, float *saved, const float *w1,
+                                const int32_t *bucket, int head_rows, float *zpart) {
+    if (int rc = ft_validate(d, "bt_ft_forward")) return rc;
+    BT_REQUIRE(w && idx && idx[0] && out && w1 && zpart, "bt_ft_forward(head): null pointer");
+    BT_REQUIRE(d->n_inputs == 1 || idx[1], "bt_ft_forward: null index pointer for input 1");
+    BT_REQUIRE(!d->pairwise || saved, "bt_ft_forward: pairwise needs a `saved` buffer");
+    BT_REQUIRE(bt_internal_ft_forward_head_ok(d, head_rows), "bt_ft_forward(head): shape not supported");
+    FtPlan p;
+    if (int rc = ft_plan(d, &p)) return rc;
+    const FtHeadSink hs{w1, bucket, head_rows, zpart};
+    return ft_forward_lds_launch(bt_stream(stream), d, p, w, bias, idx[0], d->n_inputs > 1 ? idx[1] : idx[0], out, saved,
+                                 &hs);
+}
 
 extern "C" {
 
@@ -999,40 +1122,7 @@ int bt_ft_forward(void *stream, const bt_ft_desc *d, const float *w, const float
     const int32_t *i0 = idx[0], *i1 = d->n_inputs > 1 ? idx[1] : idx[0];
     FtPlan p;
     if (int rc = ft_plan(d, &p)) return rc;
-    if (p.lds_path && !force_generic()) {
-        const long long E = (long long)d->n_inputs * d->batch;
-        int G = 256 / p.ntiles;
-        if (G < 1) G = 1;
-        long long epw = (E + G - 1) / G;
-        epw = (epw + 127) / 128 * 128;  // whole passes of 16 waves x 8 entries
-        G = (int)((E + epw - 1) / epw);
-        const int nround = (d->nnz + 31) / 32;
-        const bool al4 = d->nnz % 4 == 0 && (reinterpret_cast<uintptr_t>(i0) & 15) == 0 &&
-                         (reinterpret_cast<uintptr_t>(i1) & 15) == 0;
-        dim3 lgrid(p.ntiles * G), lblock(LDS_THREADS);
-#define FWD_LDS(PAIR, AL4, NROUND)                                                                              \
-    do {                                                                                                        \
-        if (int rc = set_lds(ft_fwd_lds<PAIR, AL4, NROUND>, p.lds_fwd_bytes)) return rc;                        \
-        BT_LAUNCH(BTK_FT_FWD_LDS, s, (ft_fwd_lds<PAIR, AL4, NROUND>), lgrid, lblock, p.lds_fwd_bytes, w, bias, i0, i1, \
-                  out, saved, *d, p.ntiles, (int)epw);                                                          \
-    } while (0)
-#define FWD_LDS2(PAIR, AL4)                                                                                     \
-    do {                                                                                                        \
-        if (nround == 1) FWD_LDS(PAIR, AL4, 1);                                                                 \
-        else FWD_LDS(PAIR, AL4, 2);                                                                             \
-    } while (0)
-        if (d->pairwise) {
-            if (al4) FWD_LDS2(true, true);
-            else FWD_LDS2(true, false);
-        } else {
-            if (al4) FWD_LDS2(false, true);
-            else FWD_LDS2(false, false);
-        }
-#undef FWD_LDS2
-#undef FWD_LDS
-        BT_LAUNCH_CHECK();
-        return BT_OK;
-    }
+    if (p.lds_path && !force_generic()) return ft_forward_lds_launch(s, d, p, w, bias, i0, i1, out, saved, nullptr);
     if (vec == 4) {
         if (d->pairwise)
             BT_LAUNCH(BTK_FT_FWD_GENERIC, s, (ft_fwd_generic<4, true>), grid, block, 0, w, bias, i0, i1, out, saved, *d);

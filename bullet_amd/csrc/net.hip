@@ -22,6 +22,7 @@ struct bt_net {
     float *gz0 = nullptr;            // [B] head pre-activation gradient (fused FT backward)
     float *loss_partials = nullptr;  // per-workgroup loss partials of the fused head forward
     int n_loss_partials = 0;
+    float *zpart = nullptr;          // [n_inputs * row tiles][B] partial head outputs of the fused FT forward
     bool fuse_loss = false, fuse_ft = false;
     float *a[BT_MAX_DENSE] = {nullptr}, *ga[BT_MAX_DENSE] = {nullptr};
     void *ft_ws = nullptr, *dense_ws = nullptr;
@@ -85,9 +86,22 @@ int check_batch(const bt_net *net, const bt_batch *b, const char *who) {
     return BT_OK;
 }
 
-int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bool want_gz0 = false) {
+int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bool want_gz0 = false,
+                 bool head_in_ft = false) {
     bt_ft_desc f = ft_desc(n, b->batch);
     const int32_t *idx[2] = {b->stm, b->nstm};
+    if (head_in_ft) {
+        // single one-output layer: its dot products are formed inside the FT forward, tile by tile, and a small
+        // finishing kernel adds the partials, the bias, the loss and its gradient
+        bt_dense_desc q = dn_desc(n, 0, b->batch);
+        const int32_t *bk = n->d.dense_bucketed[0] ? b->buckets : nullptr;
+        if (int rc = bt_internal_ft_forward_head(s, &f, n->params + n->t_off[0], n->params + n->t_off[1], idx, n->hid,
+                                                 n->saved, n->params + n->t_off[2], bk, q.buckets, n->zpart))
+            return rc;
+        return bt_internal_head_finish(s, &q, n->zpart, bt_internal_ft_head_parts(&f), n->params + n->t_off[3], bk,
+                                       b->targets, n->d.use_entry_weights ? b->entry_weights : nullptr, n->a[0],
+                                       n->grad_y, want_gz0 ? n->gz0 : nullptr, n->loss_partials, &n->n_loss_partials);
+    }
     if (int rc = bt_ft_forward(s, &f, n->params + n->t_off[0], n->params + n->t_off[1], idx, n->hid, n->saved)) return rc;
     const float *x = n->hid;
     for (int k = 0; k < n->d.n_dense; k++) {
@@ -180,6 +194,10 @@ int bt_net_create(const bt_net_desc *desc, int max_batch, float *ext_params, flo
     if ((rc = dmalloc(&n->grad_y, B))) return fail(rc);
     if ((rc = dmalloc(&n->gz0, B))) return fail(rc);
     if ((rc = dmalloc(&n->loss_partials, 1024))) return fail(rc);
+    {
+        bt_ft_desc fmax = ft_desc(n, B);
+        if ((rc = dmalloc(&n->zpart, (size_t)(bt_internal_ft_head_parts(&fmax) + 1) * B))) return fail(rc);
+    }
     for (int k = 0; k < desc->n_dense; k++) {
         if ((rc = dmalloc(&n->a[k], B * desc->dense_out[k]))) return fail(rc);
         if ((rc = dmalloc(&n->ga[k], B * desc->dense_out[k]))) return fail(rc);
@@ -210,7 +228,7 @@ int bt_net_destroy(bt_net *n) {
     if (n->own_params) bt_free(n->params);
     if (n->own_grads) bt_free(n->grads);
     bt_free(n->mom), bt_free(n->vel), bt_free(n->hid), bt_free(n->g_hid), bt_free(n->saved), bt_free(n->grad_y);
-    bt_free(n->gz0), bt_free(n->loss_partials);
+    bt_free(n->gz0), bt_free(n->loss_partials), bt_free(n->zpart);
     for (int k = 0; k < BT_MAX_DENSE; k++) bt_free(n->a[k]), bt_free(n->ga[k]);
     bt_free(n->ft_ws), bt_free(n->dense_ws);
     if (n->ev_fork) (void)hipEventDestroy(n->ev_fork);
@@ -268,7 +286,8 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
     // head's own backward (dW1, db1, final loss sum) runs on the side stream NEXT TO the FT backward -- one is
     // HBM-bound in a small-footprint kernel shape, the other LDS-bound, and they share the CUs.
     const bool side_head = fuse_loss && fuse_ft && L == 1;
-    if (int rc = forward_impl(n, s, b, fuse_loss, side_head)) return rc;
+    const bool head_in_ft = side_head && bt_internal_ft_forward_head_ok(&f, q0.buckets) && b->batch <= 1024 * 64;
+    if (int rc = forward_impl(n, s, b, fuse_loss, side_head, head_in_ft)) return rc;
     if (!fuse_loss)
         if (int rc = bt_sigmoid_mse(s, b->batch, n->a[L - 1], b->targets,
                                     n->d.use_entry_weights ? b->entry_weights : nullptr, loss_sum_dev, n->grad_y))
