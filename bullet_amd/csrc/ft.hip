@@ -608,6 +608,12 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
 // FUSED: the incoming gradient is not read from memory but formed on the fly from a one-output dense head,
 // grad_out[b][k*out_w + c] = gz[b] * W1[bucket[b]][k*out_w + c]  (Matmul::backward dX = W^T dY with a single
 // selected row, matmul.rs:117-123 + select.rs:93-110), so the [B][2H] gradient buffer never exists.
+#ifdef BT_EXP_TIMING
+__device__ unsigned long long bt_dbg[8];
+#define BT_T(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&bt_dbg[i], t_ - t_last); t_last = t_; } } while (0)
+#else
+#define BT_T(i) do { } while (0)
+#endif
 struct FtFusedSrc {
     const float *gz;        // [B] gradient w.r.t. the head's pre-activation
     const float *w1;        // head weights, column-major [w1_rows][n_inputs*out_w]
@@ -615,15 +621,13 @@ struct FtFusedSrc {
     int w1_rows;            // = number of output buckets (one output each)
 };
 
-template <bool PAIR, bool FUSED>
-__global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restrict__ grad_out, FtFusedSrc fs,
-                                                          const float *__restrict__ out,
-                                                          const float *__restrict__ saved,
-                                                          const uint16_t *__restrict__ sorted,
-                                                          const uint32_t *__restrict__ offs,
-                                                          float *__restrict__ partial_w,
-                                                          float *__restrict__ partial_b, bt_ft_desc d, int ntiles,
-                                                          int chunks_per_input, int chunks_per_wg) {
+template <bool PAIR, bool FUSED, int NSRT>
+__device__ __forceinline__ void ft_bwd_lds_body(const float *__restrict__ grad_out, const FtFusedSrc &fs,
+                                                const float *__restrict__ out, const float *__restrict__ saved,
+                                                const uint16_t *__restrict__ sorted, const uint32_t *__restrict__ offs,
+                                                float *__restrict__ partial_w, float *__restrict__ partial_b,
+                                                const bt_ft_desc &d, int ntiles, int chunks_per_input,
+                                                int chunks_per_wg) {
     extern __shared__ float lds_f[];
     float *acc = lds_f;                                   // [cols][32]
     float *gt = acc + (size_t)d.cols * LDS_RT;            // [FT_CHUNK + 1][32], last row = zeros (padding target)
@@ -661,7 +665,7 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
     // and consumed after it, so HBM latency overlaps the reduction without a second LDS buffer.
     constexpr int NPASS = FT_CHUNK / 128;
     float4 r_go[NPASS], r_a[NPASS], r_b[NPASS];
-    constexpr int NSRT = 3;  // uint4 rounds that cover the sorted list (host-checked)
+    // NSRT: uint4 rounds that cover the sorted list (host-checked)
     lds_u4_t r_srt[NSRT];  // (clang vector type: an array of HIP's uint4 struct ends up in scratch)
     uint32_t r_off[2], r_nblk = 0;
     const int srt_cap = ft_sorted_cap(d.nnz, d.cols);
@@ -708,12 +712,17 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
             r_srt[i] = gs[min(q, srt_vec - 1)];
         }
     };
+#ifdef BT_EXP_TIMING
+    unsigned long long t_last = __builtin_readcyclecounter();
+#endif
     if (c_lo < c_hi) prefetch(c_lo);
+    BT_T(0);
     for (int c = c_lo; c < c_hi; c++) {
         const int cb = c % chunks_per_input;
         const int kc = c / chunks_per_input;
         const int n_e = min(FT_CHUNK, d.batch - cb * FT_CHUNK);
         __syncthreads();  // previous chunk's readers are done with gt / srt / blkf
+        BT_T(1);
 #pragma unroll
         for (int pass = 0; pass < NPASS; pass++) {
             const int el = el0 + pass * 128;
@@ -765,11 +774,14 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
             const int qq = threadIdx.x + i * LDS_THREADS;
             if (qq < srt_vec) reinterpret_cast<lds_u4_t *>(srt)[qq] = r_srt[i];
         }
+        BT_T(2);
         __syncthreads();
+        BT_T(3);
         if (threadIdx.x == 0) span[(c + 1) & 1] = 0;  // next chunk's counters (their writers come after the next barrier)
         if (threadIdx.x < NGRP) hrank[((c + 1) & 1) * NGRP + threadIdx.x] = 0;
         if (c + 1 < c_hi) prefetch(c + 1);
 
+        BT_T(4);
         const int b0 = grp * q, b1 = min(nblk, b0 + q);
         // A run that began in an earlier group can only be the first one here: its sum is parked in h_part and
         // added after the groups before it (rank = distance to the group that owns the run's start), so every
@@ -807,8 +819,10 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
                 const bool chg = f != fcur;
                 float4 *dst = reinterpret_cast<float4 *>(acc + fcur * LDS_RT + rg_s * 4);
                 typedef float lds_f4_t __attribute__((ext_vector_type(4)));
-                // volatile: read with the gathers, not inside the branch below (where it would cost a round trip)
-                const lds_f4_t old = *(const volatile __attribute__((address_space(3))) lds_f4_t *)dst;
+                // volatile: read with the gathers, not inside the branch below (where it would cost a round trip);
+                // only the groups that end a run here take part (idle 16-lane groups cost no LDS cycle)
+                lds_f4_t old = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (chg) old = *(const volatile __attribute__((address_space(3))) lds_f4_t *)dst;
                 const float4 v0 = *reinterpret_cast<const float4 *>(gb + (w.x & 0xffffu));
                 const float4 v1 = *reinterpret_cast<const float4 *>(gb + (w.x >> 16));
                 const float4 v2 = *reinterpret_cast<const float4 *>(gb + (w.y & 0xffffu));
@@ -838,6 +852,7 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
                 }
             }
         }
+        BT_T(5);
         const int max_rank = *cur_span;  // written before the barrier above
         for (int r = 1; r <= max_rank; r++) {
             __syncthreads();
@@ -849,7 +864,9 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
             }
         }
     }
+    BT_T(6);
     __syncthreads();
+    BT_T(7);
     float *pw = partial_w + (size_t)cg * d.cols * d.stride;
     for (int q = threadIdx.x; q < d.cols * 8; q += LDS_THREADS) {
         const int f = q >> 3, t8 = q & 7;
@@ -864,6 +881,31 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds(const float *__restric
         for (int i = 0; i < 128; i++) s += gt[i * LDS_RT + threadIdx.x];
         partial_b[(size_t)cg * d.rows + tile_row(PAIR, rt, half_rows, threadIdx.x)] = s;
     }
+}
+
+// Non-pairwise tables whose chunk list fits two staging rounds (Chess768, Ataxx): held to 96 VGPRs, so that four
+// waves per SIMD leave room for one wave of dense_bwd_small_light -- net.hip runs the head's weight-gradient
+// pass next to this kernel.
+template <bool FUSED>
+__global__ __launch_bounds__(LDS_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) void ft_bwd_lds(
+    const float *__restrict__ grad_out, FtFusedSrc fs, const float *__restrict__ out, const float *__restrict__ saved,
+    const uint16_t *__restrict__ sorted, const uint32_t *__restrict__ offs, float *__restrict__ partial_w,
+    float *__restrict__ partial_b, bt_ft_desc d, int ntiles, int chunks_per_input, int chunks_per_wg) {
+    ft_bwd_lds_body<false, FUSED, 2>(grad_out, fs, out, saved, sorted, offs, partial_w, partial_b, d, ntiles,
+                                     chunks_per_input, chunks_per_wg);
+}
+
+template <bool PAIR, bool FUSED>
+__global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds_any(const float *__restrict__ grad_out, FtFusedSrc fs,
+                                                              const float *__restrict__ out,
+                                                              const float *__restrict__ saved,
+                                                              const uint16_t *__restrict__ sorted,
+                                                              const uint32_t *__restrict__ offs,
+                                                              float *__restrict__ partial_w,
+                                                              float *__restrict__ partial_b, bt_ft_desc d, int ntiles,
+                                                              int chunks_per_input, int chunks_per_wg) {
+    ft_bwd_lds_body<PAIR, FUSED, 3>(grad_out, fs, out, saved, sorted, offs, partial_w, partial_b, d, ntiles,
+                                    chunks_per_input, chunks_per_wg);
 }
 
 // dw[f][offset + r] = sum_g partial_w[g][f][offset + r] (fixed order); dbias likewise
@@ -982,18 +1024,22 @@ int ft_backward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, 
     dim3 grid(p.ntiles * p.G), block(LDS_THREADS);
     const bool fused = fs.gz != nullptr;
     const size_t lds = p.lds_bwd_bytes + (fused ? (size_t)d->n_inputs * fs.w1_rows * 32 * sizeof(float) : 0);
-#define BWD_LDS(PAIR, FUSED)                                                                                        \
+    const bool lean = !d->pairwise && ft_sorted_cap(d->nnz, d->cols) / 8 <= 2 * LDS_THREADS;
+#define BWD_LDS(KERNEL)                                                                                             \
     do {                                                                                                            \
-        if (int rc = set_lds(ft_bwd_lds<PAIR, FUSED>, lds)) return rc;                                              \
-        BT_LAUNCH(BTK_FT_BWD_LDS, s, (ft_bwd_lds<PAIR, FUSED>), grid, block, lds, grad_out, fs, out, saved, sorted, offs, \
-                  pw, pb, *d, p.ntiles, p.chunks_per_input, p.chunks_per_wg);                                       \
+        if (int rc = set_lds(KERNEL, lds)) return rc;                                                               \
+        BT_LAUNCH(BTK_FT_BWD_LDS, s, (KERNEL), grid, block, lds, grad_out, fs, out, saved, sorted, offs, pw, pb, *d,  \
+                  p.ntiles, p.chunks_per_input, p.chunks_per_wg);                                                   \
     } while (0)
-    if (d->pairwise) {
-        if (fused) BWD_LDS(true, true);
-        else BWD_LDS(true, false);
+    if (lean) {
+        if (fused) BWD_LDS(ft_bwd_lds<true>);
+        else BWD_LDS(ft_bwd_lds<false>);
+    } else if (d->pairwise) {
+        if (fused) BWD_LDS((ft_bwd_lds_any<true, true>));
+        else BWD_LDS((ft_bwd_lds_any<true, false>));
     } else {
-        if (fused) BWD_LDS(false, true);
-        else BWD_LDS(false, false);
+        if (fused) BWD_LDS((ft_bwd_lds_any<false, true>));
+        else BWD_LDS((ft_bwd_lds_any<false, false>));
     }
 #undef BWD_LDS
     BT_LAUNCH_CHECK();
@@ -1105,6 +1151,15 @@ int bt_internal_ft_forward_head(void *stream, const bt_ft_desc *d, const float *
     return ft_forward_lds_launch(bt_stream(stream), d, p, w, bias, idx[0], d->n_inputs > 1 ? idx[1] : idx[0], out, saved,
                                  &hs);
 }
+
+#ifdef BT_EXP_TIMING
+extern "C" int bt_debug_read(unsigned long long *out) {
+    BT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(bt_dbg), sizeof(unsigned long long) * 8));
+    unsigned long long z[8] = {0};
+    BT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(bt_dbg), z, sizeof(z)));
+    return 0;
+}
+#endif
 
 extern "C" {
 
