@@ -608,6 +608,9 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
 // FUSED: the incoming gradient is not read from memory but formed on the fly from a one-output dense head,
 // grad_out[b][k*out_w + c] = gz[b] * W1[bucket[b]][k*out_w + c]  (Matmul::backward dX = W^T dY with a single
 // selected row, matmul.rs:117-123 + select.rs:93-110), so the [B][2H] gradient buffer never exists.
+#ifdef BT_EXP_TIMING2
+__device__ unsigned long long bt_dbg2[16];
+#endif
 #ifdef BT_EXP_TIMING
 __device__ unsigned long long bt_dbg[8];
 #define BT_T(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&bt_dbg[i], t_ - t_last); t_last = t_; } } while (0)
@@ -782,6 +785,9 @@ __device__ __forceinline__ void ft_bwd_lds_body(const float *__restrict__ grad_o
         if (c + 1 < c_hi) prefetch(c + 1);
 
         BT_T(4);
+#ifdef BT_EXP_TIMING2
+        unsigned long long tw0 = __builtin_readcyclecounter();
+#endif
         const int b0 = grp * q, b1 = min(nblk, b0 + q);
         // A run that began in an earlier group can only be the first one here: its sum is parked in h_part and
         // added after the groups before it (rank = distance to the group that owns the run's start), so every
@@ -852,6 +858,9 @@ __device__ __forceinline__ void ft_bwd_lds_body(const float *__restrict__ grad_o
                 }
             }
         }
+#ifdef BT_EXP_TIMING2
+        if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) atomicAdd(&bt_dbg2[threadIdx.x >> 6], __builtin_readcyclecounter() - tw0);
+#endif
         BT_T(5);
         const int max_rank = *cur_span;  // written before the barrier above
         for (int r = 1; r <= max_rank; r++) {
@@ -1152,6 +1161,12 @@ int bt_internal_ft_forward_head(void *stream, const bt_ft_desc *d, const float *
                                  &hs);
 }
 
+#ifdef BT_EXP_TIMING2
+extern "C" int bt_debug_read2(unsigned long long *out) {
+    BT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(bt_dbg2), sizeof(unsigned long long) * 16));
+    return 0;
+}
+#endif
 #ifdef BT_EXP_TIMING
 extern "C" int bt_debug_read(unsigned long long *out) {
     BT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(bt_dbg), sizeof(unsigned long long) * 8));

@@ -19,3 +19,8 @@ names = ["prologue", "top barrier wait", "staging (LDS writes, blkf)", "barrier 
 tot = sum(buf)
 for n, v in zip(names, buf):
     print(f"{n:28s} {v/25:12.0f} cycles/launch  {100*v/tot:5.1f}%")
+
+if hasattr(L, "bt_debug_read2"):
+    b2 = (C.c_ulonglong * 16)()
+    L.bt_debug_read2(b2)
+    print("reduce-loop cycles per launch by wave:", [int(v / 25) for v in b2])
