@@ -4,6 +4,7 @@
 // (FT fwd x perspectives -> dense stack with bucket select -> sigmoid-MSE -> dense bwd -> FT bwd -> AdamW).
 // All buffers are allocated once in bt_net_create (Function::prealloc, function.rs:180-196);
 // a step only enqueues kernels on the caller's stream -- no host sync, no allocation.
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -25,6 +26,10 @@ struct bt_net {
     float *zpart = nullptr;          // [n_inputs * row tiles][B] partial head outputs of the fused FT forward
     bool fuse_loss = false, fuse_ft = false;
     float *a[BT_MAX_DENSE] = {nullptr}, *ga[BT_MAX_DENSE] = {nullptr};
+    // layers with a dual activation / skip neurons: a[k] holds the raw outputs z, ap[k] what the next layer sees,
+    // gzp[k] the gradient w.r.t. z; yfin = last layer + skip neurons; weff = l0w + l0f.repeat(NB)
+    float *ap[BT_MAX_DENSE] = {nullptr}, *gzp[BT_MAX_DENSE] = {nullptr};
+    float *yfin = nullptr, *weff = nullptr;
     void *ft_ws = nullptr, *dense_ws = nullptr;
     // side stream: the FT sorted index (depends only on the batch indices) is built while the forward runs
     hipStream_t side = nullptr;
@@ -42,13 +47,34 @@ int net_validate(const bt_net_desc *d) {
     BT_REQUIRE(d->num_buckets >= 1, "bt_net: num_buckets must be >= 1");
     BT_REQUIRE(!d->pairwise || d->ft_out % 2 == 0, "bt_net: pairwise needs even ft_out");
     BT_REQUIRE(d->dense_out[d->n_dense - 1] == 1, "bt_net: last layer must have one output per bucket");
-    BT_REQUIRE(2 + 2 * d->n_dense <= BT_ADAMW_MAX_TENSORS, "bt_net: too many tensors");
+    BT_REQUIRE(2 + 2 * d->n_dense + (d->ft_factoriser > 0) <= BT_ADAMW_MAX_TENSORS, "bt_net: too many tensors");
+    BT_REQUIRE(d->ft_factoriser >= 0 && (d->ft_factoriser == 0 || d->num_inputs % d->ft_factoriser == 0),
+               "bt_net: ft_factoriser must divide num_inputs");
+    int skips = 0;
+    for (int k = 0; k < d->n_dense; k++) {
+        BT_REQUIRE(d->dense_skip[k] >= 0 && d->dense_skip[k] < d->dense_out[k], "bt_net: bad dense_skip[%d]", k);
+        BT_REQUIRE(k < d->n_dense - 1 || (d->dense_skip[k] == 0 && d->dense_dual[k] == 0),
+                   "bt_net: the last layer cannot have skip neurons or a dual activation");
+        skips += d->dense_skip[k];
+    }
+    BT_REQUIRE(skips == 0 || skips == d->dense_out[d->n_dense - 1], "bt_net: skip neurons must match the net output");
+    for (int k = 0; k < d->n_dense; k++)
+        BT_REQUIRE(d->dense_skip[k] == 0 || d->dense_skip[k] == skips, "bt_net: one layer may own the skip neurons");
     return BT_OK;
 }
 
+bool has_post(const bt_net_desc *d, int k) { return d->dense_dual[k] || d->dense_skip[k]; }
+bool has_skip(const bt_net_desc *d) {
+    for (int k = 0; k < d->n_dense; k++)
+        if (d->dense_skip[k]) return true;
+    return false;
+}
+// width of what the next layer sees of layer k
+int dense_width(const bt_net_desc *d, int k) { return (d->dense_out[k] - d->dense_skip[k]) * (d->dense_dual[k] ? 2 : 1); }
+
 int dense_in(const bt_net_desc *d, int k) {
     if (k == 0) return d->perspectives * (d->pairwise ? d->ft_out / 2 : d->ft_out);
-    return d->dense_out[k - 1];
+    return dense_width(d, k - 1);
 }
 int dense_rows(const bt_net_desc *d, int k) { return d->dense_out[k] * (d->dense_bucketed[k] ? d->num_buckets : 1); }
 
@@ -64,8 +90,84 @@ bt_dense_desc dn_desc(const bt_net *n, int k, int batch) {
     const bt_net_desc &d = n->d;
     bt_dense_desc q;
     q.batch = batch, q.in = dense_in(&d, k), q.out = d.dense_out[k];
-    q.buckets = d.dense_bucketed[k] ? d.num_buckets : 1, q.act = d.dense_act[k];
+    q.buckets = d.dense_bucketed[k] ? d.num_buckets : 1;
+    q.act = has_post(&d, k) ? BT_ACT_IDENTITY : d.dense_act[k];  // post-op layers are activated by head_post_fwd
     return q;
+}
+
+// ---- small elementwise kernels of the extended head (dual activation, skip neurons) and the factoriser
+__global__ void factor_expand_kernel(const float4 *__restrict__ w, const float4 *__restrict__ wf, float4 *__restrict__ weff,
+                                     size_t n4, size_t fc4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 a = w[i], b = wf[i % fc4];  // repeat(NB): bucketed column c uses factoriser column c mod (F/NB)
+    weff[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+__global__ void factor_reduce_kernel(const float4 *__restrict__ dw, float4 *__restrict__ dwf, size_t fc4, int reps) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= fc4) return;
+    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // Broadcast(Cols) backward = sum over the repeats, ascending
+    for (int r = 0; r < reps; r++) {
+        const float4 v = dw[(size_t)r * fc4 + i];
+        s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+    dwf[i] = s;
+}
+
+// z [B][out] -> ap [B][wd]: first m = out - skip rows, optionally widened to concat(x, x*x), then activated
+__global__ void head_post_fwd_kernel(const float *__restrict__ z, float *__restrict__ ap, int batch, int out, int m,
+                                     int dual, int act) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * m) return;
+    const int b = t / m, i = t - b * m, wd = dual ? 2 * m : m;
+    const float v = z[(size_t)b * out + i];
+    ap[(size_t)b * wd + i] = bt_act_fwd(act, v);
+    if (dual) ap[(size_t)b * wd + m + i] = bt_act_fwd(act, v * v);
+}
+
+// gradient w.r.t. z from the gradient w.r.t. ap (activation backward from the output, Concat/Slice backward, Mul
+// backward with both operands x: contributions in reverse creation order) and, for the skip rows, w.r.t. the output
+__global__ void head_post_bwd_kernel(const float *__restrict__ gap, const float *__restrict__ ap,
+                                     const float *__restrict__ z, const float *__restrict__ gy, float *__restrict__ gz,
+                                     int batch, int out, int m, int dual, int act, int n_out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * out) return;
+    const int b = t / out, i = t - b * out, wd = dual ? 2 * m : m;
+    float g;
+    if (i < m) {
+        g = gap[(size_t)b * wd + i] * bt_act_deriv(act, ap[(size_t)b * wd + i]);
+        if (dual) {
+            const float g2 = gap[(size_t)b * wd + m + i] * bt_act_deriv(act, ap[(size_t)b * wd + m + i]);
+            const float xv = z[(size_t)b * out + i];
+            g = (g + g2 * xv) + g2 * xv;
+        }
+    } else {
+        g = gy[(size_t)b * n_out + (i - m)];
+    }
+    gz[t] = g;
+}
+
+// y[b][j] += z[b][out - skip + j]
+__global__ void head_skip_add_kernel(float *__restrict__ y, const float *__restrict__ z, int batch, int out, int skip) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * skip) return;
+    const int b = t / skip, j = t - b * skip;
+    y[t] = y[t] + z[(size_t)b * out + out - skip + j];
+}
+
+// the table the FT runs on: l0w, or l0w + l0f.repeat(NB) rebuilt for this step
+int ft_weights(bt_net *n, hipStream_t s, const float **w0) {
+    *w0 = n->params + n->t_off[0];
+    if (n->d.ft_factoriser <= 0) return BT_OK;
+    const size_t n4 = n->t_size[0] / 4, fc4 = n4 / n->d.ft_factoriser;
+    factor_expand_kernel<<<dim3((unsigned)bt_div_up((long long)n4, 256)), dim3(256), 0, s>>>(
+        reinterpret_cast<const float4 *>(n->params + n->t_off[0]),
+        reinterpret_cast<const float4 *>(n->params + n->t_off[n->n_tensors - 1]), reinterpret_cast<float4 *>(n->weff), n4,
+        fc4);
+    BT_LAUNCH_CHECK();
+    *w0 = n->weff;
+    return BT_OK;
 }
 
 int dmalloc(float **p, size_t floats) {
@@ -90,19 +192,21 @@ int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bo
                  bool head_in_ft = false) {
     bt_ft_desc f = ft_desc(n, b->batch);
     const int32_t *idx[2] = {b->stm, b->nstm};
+    const float *w0 = nullptr;
+    if (int rc = ft_weights(n, s, &w0)) return rc;
     if (head_in_ft) {
         // single one-output layer: its dot products are formed inside the FT forward, tile by tile, and a small
         // finishing kernel adds the partials, the bias, the loss and its gradient
         bt_dense_desc q = dn_desc(n, 0, b->batch);
         const int32_t *bk = n->d.dense_bucketed[0] ? b->buckets : nullptr;
-        if (int rc = bt_internal_ft_forward_head(s, &f, n->params + n->t_off[0], n->params + n->t_off[1], idx, n->hid,
+        if (int rc = bt_internal_ft_forward_head(s, &f, w0, n->params + n->t_off[1], idx, n->hid,
                                                  n->saved, n->params + n->t_off[2], bk, q.buckets, n->zpart))
             return rc;
         return bt_internal_head_finish(s, &q, n->zpart, bt_internal_ft_head_parts(&f), n->params + n->t_off[3], bk,
                                        b->targets, n->d.use_entry_weights ? b->entry_weights : nullptr, n->a[0],
                                        n->grad_y, want_gz0 ? n->gz0 : nullptr, n->loss_partials, &n->n_loss_partials);
     }
-    if (int rc = bt_ft_forward(s, &f, n->params + n->t_off[0], n->params + n->t_off[1], idx, n->hid, n->saved)) return rc;
+    if (int rc = bt_ft_forward(s, &f, w0, n->params + n->t_off[1], idx, n->hid, n->saved)) return rc;
     const float *x = n->hid;
     for (int k = 0; k < n->d.n_dense; k++) {
         bt_dense_desc q = dn_desc(n, k, b->batch);
@@ -117,18 +221,38 @@ int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bo
                                              b->buckets, n->a[k]))
             return rc;
         x = n->a[k];
+        if (has_post(&n->d, k)) {
+            const int m = q.out - n->d.dense_skip[k];
+            head_post_fwd_kernel<<<dim3((unsigned)bt_div_up((long long)b->batch * m, 256)), dim3(256), 0, s>>>(
+                n->a[k], n->ap[k], b->batch, q.out, m, n->d.dense_dual[k], n->d.dense_act[k]);
+            BT_LAUNCH_CHECK();
+            x = n->ap[k];
+        }
+    }
+    if (has_skip(&n->d)) {  // net output = last layer + skip neurons
+        const int L = n->d.n_dense, n_out = n->d.dense_out[L - 1];
+        BT_HIP(hipMemcpyAsync(n->yfin, n->a[L - 1], sizeof(float) * b->batch * n_out, hipMemcpyDeviceToDevice, s));
+        for (int k = 0; k < L - 1; k++)
+            if (n->d.dense_skip[k]) {
+                head_skip_add_kernel<<<dim3((unsigned)bt_div_up((long long)b->batch * n_out, 256)), dim3(256), 0, s>>>(
+                    n->yfin, n->a[k], b->batch, n->d.dense_out[k], n->d.dense_skip[k]);
+                BT_LAUNCH_CHECK();
+            }
     }
     return BT_OK;
 }
+
+const float *net_output(const bt_net *n) { return has_skip(&n->d) ? n->yfin : n->a[n->d.n_dense - 1]; }
 
 }  // namespace
 
 extern "C" {
 
-int bt_net_num_tensors(const bt_net_desc *d) { return d ? 2 + 2 * d->n_dense : 0; }
+int bt_net_num_tensors(const bt_net_desc *d) { return d ? 2 + 2 * d->n_dense + (d->ft_factoriser > 0 ? 1 : 0) : 0; }
 
 size_t bt_net_tensor_size(const bt_net_desc *d, int t) {
-    if (!d || t < 0 || t >= 2 + 2 * d->n_dense) return 0;
+    if (!d || t < 0 || t >= bt_net_num_tensors(d)) return 0;
+    if (t == 2 + 2 * d->n_dense) return (size_t)d->ft_out * (d->num_inputs / d->ft_factoriser);  // l0f
     if (t == 0) return (size_t)d->ft_out * d->num_inputs;
     if (t == 1) return (size_t)d->ft_out;
     const int k = (t - 2) / 2;
@@ -198,9 +322,16 @@ int bt_net_create(const bt_net_desc *desc, int max_batch, float *ext_params, flo
         bt_ft_desc fmax = ft_desc(n, B);
         if ((rc = dmalloc(&n->zpart, (size_t)(bt_internal_ft_head_parts(&fmax) + 1) * B))) return fail(rc);
     }
+    if (desc->ft_factoriser > 0 && (rc = dmalloc(&n->weff, n->t_size[0]))) return fail(rc);
+    if (has_skip(desc) && (rc = dmalloc(&n->yfin, B * desc->dense_out[desc->n_dense - 1]))) return fail(rc);
     for (int k = 0; k < desc->n_dense; k++) {
+        const size_t wide = (size_t)std::max(desc->dense_out[k], dense_width(desc, k));
         if ((rc = dmalloc(&n->a[k], B * desc->dense_out[k]))) return fail(rc);
-        if ((rc = dmalloc(&n->ga[k], B * desc->dense_out[k]))) return fail(rc);
+        if ((rc = dmalloc(&n->ga[k], B * wide))) return fail(rc);
+        if (has_post(desc, k)) {
+            if ((rc = dmalloc(&n->ap[k], B * dense_width(desc, k)))) return fail(rc);
+            if ((rc = dmalloc(&n->gzp[k], B * desc->dense_out[k]))) return fail(rc);
+        }
         bt_dense_desc q = dn_desc(n, k, max_batch);
         size_t wsb = bt_dense_backward_workspace_bytes(&q);
         if (wsb == 0) return fail(BT_ERR_INVALID);
@@ -229,7 +360,8 @@ int bt_net_destroy(bt_net *n) {
     if (n->own_grads) bt_free(n->grads);
     bt_free(n->mom), bt_free(n->vel), bt_free(n->hid), bt_free(n->g_hid), bt_free(n->saved), bt_free(n->grad_y);
     bt_free(n->gz0), bt_free(n->loss_partials), bt_free(n->zpart);
-    for (int k = 0; k < BT_MAX_DENSE; k++) bt_free(n->a[k]), bt_free(n->ga[k]);
+    for (int k = 0; k < BT_MAX_DENSE; k++) bt_free(n->a[k]), bt_free(n->ga[k]), bt_free(n->ap[k]), bt_free(n->gzp[k]);
+    bt_free(n->yfin), bt_free(n->weff);
     bt_free(n->ft_ws), bt_free(n->dense_ws);
     if (n->ev_fork) (void)hipEventDestroy(n->ev_fork);
     if (n->ev_index) (void)hipEventDestroy(n->ev_index);
@@ -257,7 +389,7 @@ int bt_net_forward(bt_net *n, void *stream, const bt_batch *b, float *out_dev, f
     if (int rc = check_batch(n, b, "bt_net_forward")) return rc;
     hipStream_t s = bt_stream(stream);
     if (int rc = forward_impl(n, s, b, false)) return rc;
-    const float *y = n->a[n->d.n_dense - 1];
+    const float *y = net_output(n);
     if (out_dev) BT_HIP(hipMemcpyAsync(out_dev, y, sizeof(float) * b->batch, hipMemcpyDeviceToDevice, s));
     if (loss_sum_dev)
         return bt_sigmoid_mse(s, b->batch, y, b->targets, n->d.use_entry_weights ? b->entry_weights : nullptr,
@@ -280,8 +412,9 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
     // fusion decisions (shape-dependent, see dense.hip / ft.hip): loss into the final head's forward, the head's dX
     // into the FT backward staging
     bt_dense_desc q_last = dn_desc(n, L - 1, b->batch), q0 = dn_desc(n, 0, b->batch);
-    const bool fuse_loss = bt_internal_dense_forward_loss_ok(&q_last) && bt_internal_dense_head_ok(&q_last);
-    const bool fuse_ft = bt_internal_dense_head_ok(&q0) && bt_internal_ft_fused_ok(&f, q0.buckets);
+    const bool fuse_loss = bt_internal_dense_forward_loss_ok(&q_last) && bt_internal_dense_head_ok(&q_last) &&
+                           !has_skip(&n->d);  // with skip neurons the loss is taken from yfin, not the last layer
+    const bool fuse_ft = bt_internal_dense_head_ok(&q0) && bt_internal_ft_fused_ok(&f, q0.buckets) && !has_post(&n->d, 0);
     // Single-layer head with both fusions: the forward already produced gz (all the FT backward needs), so the
     // head's own backward (dW1, db1, final loss sum) runs on the side stream NEXT TO the FT backward -- one is
     // HBM-bound in a small-footprint kernel shape, the other LDS-bound, and they share the CUs.
@@ -289,9 +422,19 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
     const bool head_in_ft = side_head && bt_internal_ft_forward_head_ok(&f, q0.buckets) && b->batch <= 1024 * 64;
     if (int rc = forward_impl(n, s, b, fuse_loss, side_head, head_in_ft)) return rc;
     if (!fuse_loss)
-        if (int rc = bt_sigmoid_mse(s, b->batch, n->a[L - 1], b->targets,
+        if (int rc = bt_sigmoid_mse(s, b->batch, net_output(n), b->targets,
                                     n->d.use_entry_weights ? b->entry_weights : nullptr, loss_sum_dev, n->grad_y))
             return rc;
+    // gradient of the factoriser: sum of the table gradient over the repeats (after the FT backward wrote it)
+    auto factor_reduce = [&]() -> int {
+        if (n->d.ft_factoriser <= 0) return BT_OK;
+        const size_t fc4 = n->t_size[0] / 4 / n->d.ft_factoriser;
+        factor_reduce_kernel<<<dim3((unsigned)bt_div_up((long long)fc4, 256)), dim3(256), 0, s>>>(
+            reinterpret_cast<const float4 *>(n->grads + n->t_off[0]),
+            reinterpret_cast<float4 *>(n->grads + n->t_off[n->n_tensors - 1]), fc4, n->d.ft_factoriser);
+        BT_LAUNCH_CHECK();
+        return BT_OK;
+    };
     if (side_head) {
         BT_HIP(hipEventRecord(n->ev_fwd, s));
         BT_HIP(hipStreamWaitEvent(n->side, n->ev_fwd, 0));  // side: after the index build (stream order) and the forward
@@ -307,13 +450,23 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
                                                    n->saved, n->grads + n->t_off[0], n->grads + n->t_off[1], n->ft_ws,
                                                    n->ft_ws_bytes))
             return rc;
+        if (int rc = factor_reduce()) return rc;
         BT_HIP(hipStreamWaitEvent(s, n->ev_head, 0));  // the step's gradients and loss are complete on `s`
         return BT_OK;
     }
     for (int k = L - 1; k >= 0; k--) {
         bt_dense_desc q = dn_desc(n, k, b->batch);
-        const float *x = (k == 0) ? n->hid : n->a[k - 1];
+        const float *x = (k == 0) ? n->hid : (has_post(&n->d, k - 1) ? n->ap[k - 1] : n->a[k - 1]);
         const float *gy = (k == L - 1) ? n->grad_y : n->ga[k];
+        if (k < L - 1 && has_post(&n->d, k)) {
+            // ga[k] is the gradient w.r.t. what layer k+1 saw; turn it into the gradient w.r.t. layer k's raw outputs
+            const int m = q.out - n->d.dense_skip[k];
+            head_post_bwd_kernel<<<dim3((unsigned)bt_div_up((long long)b->batch * q.out, 256)), dim3(256), 0, s>>>(
+                n->ga[k], n->ap[k], n->a[k], n->grad_y, n->gzp[k], b->batch, q.out, m, n->d.dense_dual[k],
+                n->d.dense_act[k], n->d.dense_out[L - 1]);
+            BT_LAUNCH_CHECK();
+            gy = n->gzp[k];
+        }
         float *gx = (k == 0) ? n->g_hid : n->ga[k - 1];
         float *dwk = n->grads + n->t_off[2 + 2 * k], *dbk = n->grads + n->t_off[3 + 2 * k];
         const float *wk = n->params + n->t_off[2 + 2 * k];
@@ -330,12 +483,16 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
             return rc;
     }
     BT_HIP(hipStreamWaitEvent(s, n->ev_index, 0));  // join
-    if (fuse_ft)
-        return bt_internal_ft_backward_fused(s, &f, n->gz0, n->params + n->t_off[2],
-                                             n->d.dense_bucketed[0] ? b->buckets : nullptr, q0.buckets, n->hid, n->saved,
-                                             n->grads + n->t_off[0], n->grads + n->t_off[1], n->ft_ws, n->ft_ws_bytes);
-    return bt_ft_backward_prebuilt(s, &f, n->g_hid, n->hid, n->saved, n->grads + n->t_off[0], n->grads + n->t_off[1],
-                                   n->ft_ws, n->ft_ws_bytes);
+    if (fuse_ft) {
+        if (int rc = bt_internal_ft_backward_fused(s, &f, n->gz0, n->params + n->t_off[2],
+                                                   n->d.dense_bucketed[0] ? b->buckets : nullptr, q0.buckets, n->hid,
+                                                   n->saved, n->grads + n->t_off[0], n->grads + n->t_off[1], n->ft_ws,
+                                                   n->ft_ws_bytes))
+            return rc;
+    } else if (int rc = bt_ft_backward_prebuilt(s, &f, n->g_hid, n->hid, n->saved, n->grads + n->t_off[0],
+                                                n->grads + n->t_off[1], n->ft_ws, n->ft_ws_bytes))
+        return rc;
+    return factor_reduce();
 }
 
 int bt_net_optimiser_step(bt_net *n, void *stream, const float *adj_dev, const float *lr_dev) {

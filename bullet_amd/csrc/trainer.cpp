@@ -85,7 +85,8 @@ struct Ziggurat {
 };
 
 int dense_in_of(const bt_net_desc *d, int k) {
-    return k == 0 ? d->perspectives * (d->pairwise ? d->ft_out / 2 : d->ft_out) : d->dense_out[k - 1];
+    if (k == 0) return d->perspectives * (d->pairwise ? d->ft_out / 2 : d->ft_out);
+    return (d->dense_out[k - 1] - d->dense_skip[k - 1]) * (d->dense_dual[k - 1] ? 2 : 1);
 }
 
 }  // namespace
@@ -96,7 +97,8 @@ extern "C" int bt_net_init_weights_host(const bt_net_desc *d, uint64_t seed, int
     Xoroshiro128Plus rng(seed);
     const int nt = bt_net_num_tensors(d);
     std::memset(flat, 0, bt_net_param_count(d) * sizeof(float));
-    for (int t = 0; t < nt; t += 2) {  // even tensors = weights; biases (odd) stay zero and consume no RNG
+    const int nw = 2 + 2 * d->n_dense;  // a factoriser (last tensor) is InitSettings::Zeroed like the biases
+    for (int t = 0; t < nw && t < nt; t += 2) {  // even tensors = weights; biases (odd) stay zero and consume no RNG
         const size_t n = bt_net_tensor_size(d, t);
         float *dst = flat + bt_net_tensor_offset(d, t);
         const int in = (t == 0) ? (ft_eff > 0 ? ft_eff : d->num_inputs) : dense_in_of(d, (t - 2) / 2);

@@ -37,6 +37,7 @@ class NetDesc(C.Structure):
         ("pairwise", C.c_int), ("perspectives", C.c_int), ("num_buckets", C.c_int), ("n_dense", C.c_int),
         ("dense_out", C.c_int * MAX_DENSE), ("dense_act", C.c_int * MAX_DENSE),
         ("dense_bucketed", C.c_int * MAX_DENSE), ("use_entry_weights", C.c_int),
+        ("ft_factoriser", C.c_int), ("dense_dual", C.c_int * MAX_DENSE), ("dense_skip", C.c_int * MAX_DENSE),
     ]
 
 
@@ -189,14 +190,18 @@ def profile_stop():
 
 
 def make_net_desc(num_inputs, nnz, ft_out, ft_act, dense, pairwise=False, perspectives=2, num_buckets=1,
-                  use_entry_weights=False):
-    """dense: list of (out_per_bucket, act_name, bucketed)"""
+                  use_entry_weights=False, ft_factoriser=0):
+    """dense: list of (out_per_bucket, act_name, bucketed[, dual[, skip]]); ft_factoriser = NB repeats of l0f"""
     d = NetDesc()
     d.num_inputs, d.nnz, d.ft_out, d.ft_act = num_inputs, nnz, ft_out, ACT[ft_act]
     d.pairwise, d.perspectives, d.num_buckets, d.n_dense = int(pairwise), perspectives, num_buckets, len(dense)
-    for k, (o, a, bk) in enumerate(dense):
+    for k, spec in enumerate(dense):
+        o, a, bk = spec[:3]
         d.dense_out[k], d.dense_act[k], d.dense_bucketed[k] = o, ACT[a], int(bk)
+        d.dense_dual[k] = int(spec[3]) if len(spec) > 3 else 0
+        d.dense_skip[k] = int(spec[4]) if len(spec) > 4 else 0
     d.use_entry_weights = int(use_entry_weights)
+    d.ft_factoriser = ft_factoriser
     return d
 
 

@@ -202,6 +202,14 @@ typedef struct {
     int dense_act[BT_MAX_DENSE];
     int dense_bucketed[BT_MAX_DENSE];
     int use_entry_weights;
+    /* extensions (zero = off) used by examples/tests/test2.rs and examples/progression/3_input_buckets.rs */
+    int ft_factoriser;            /* NB > 0: the FT runs on l0w + l0f.repeat(NB), l0f = [ft_out x num_inputs/NB] is one
+                                     more weight tensor, stored LAST (3_input_buckets.rs:62-67; Broadcast(Cols),
+                                     crates/compiler/src/model/operations/linear.rs:37-55) */
+    int dense_dual[BT_MAX_DENSE]; /* 1: layer output x -> concat(x, x*x) before its activation (test2.rs:58) */
+    int dense_skip[BT_MAX_DENSE]; /* s: the last s outputs of layer k are sliced off and added to the net output
+                                     (slice_rows + `out + skip_neuron`, test2.rs:54-64); next layer sees
+                                     (dense_out - s) * (dual ? 2 : 1) inputs */
 } bt_net_desc;
 
 typedef struct bt_net bt_net; /* opaque: weights, AdamW state, gradients, activations, scratch */

@@ -174,11 +174,16 @@ void orc_adamw(float *p, float *m, float *v, const float *g, size_t n, float adj
 
 /* ====================================================================== net */
 
-int orc_net_num_tensors(const orc_net_desc *d) { return 2 + 2 * d->n_dense; }
+int orc_net_num_tensors(const orc_net_desc *d) { return 2 + 2 * d->n_dense + (d->ft_factoriser > 0 ? 1 : 0); }
+
+/* width of the activated output of dense layer k (what the next layer sees) */
+static int dense_width(const orc_net_desc *d, int k) {
+    return (d->dense_out[k] - d->dense_skip[k]) * (d->dense_dual[k] ? 2 : 1);
+}
 
 int orc_net_dense_in(const orc_net_desc *d, int k) {
     if (k == 0) return d->perspectives * (d->pairwise ? d->ft_out / 2 : d->ft_out);
-    return d->dense_out[k - 1];
+    return dense_width(d, k - 1);
 }
 
 static int dense_rows_full(const orc_net_desc *d, int k) {
@@ -186,6 +191,7 @@ static int dense_rows_full(const orc_net_desc *d, int k) {
 }
 
 size_t orc_net_tensor_size(const orc_net_desc *d, int t) {
+    if (d->ft_factoriser > 0 && t == 2 + 2 * d->n_dense) return (size_t)d->ft_out * (d->num_inputs / d->ft_factoriser);
     if (t == 0) return (size_t)d->ft_out * d->num_inputs;
     if (t == 1) return (size_t)d->ft_out;
     int k = (t - 2) / 2;
@@ -197,9 +203,22 @@ typedef struct {
     /* per perspective */
     float *c[2];   /* activated FT rows [B][H] (pairwise: CReLU'd halves; else act output) */
     float *hid;    /* concat hidden [B][K0] */
-    float *a[ORC_MAX_DENSE];  /* activated output of dense k: [B][out_k] */
+    float *a[ORC_MAX_DENSE];  /* activated output of dense k: [B][width_k] */
+    float *z[ORC_MAX_DENSE];  /* pre-activation output of dense k: [B][out_k] (kept for dual / skip layers) */
+    float *y;      /* net output [B][out_last] = a[last] + skip neurons */
+    float *weff;   /* l0w + repeat(l0f) when the net has a factoriser */
     float *sig;    /* sigmoid(y) [B] */
 } orc_acts;
+
+/* W_eff = l0w + l0f.repeat(NB): column c of the bucketed table gets factoriser column c mod (F/NB) */
+static float *factorised_weights(const orc_net_desc *d, const float *const *params) {
+    const int H = d->ft_out, F = d->num_inputs, Fc = F / d->ft_factoriser;
+    const float *w0 = params[0], *wf = params[2 + 2 * d->n_dense];
+    float *we = (float *)malloc(sizeof(float) * (size_t)H * F);
+    for (int c = 0; c < F; c++)
+        for (int r = 0; r < H; r++) we[(size_t)c * H + r] = w0[(size_t)c * H + r] + wf[(size_t)(c % Fc) * H + r];
+    return we;
+}
 
 static float net_forward_impl(const orc_net_desc *d, int B, const float *const *params, const int32_t *stm,
                               const int32_t *nstm, const int32_t *buckets, const float *targets,
@@ -209,6 +228,7 @@ static float net_forward_impl(const orc_net_desc *d, int B, const float *const *
     const int K0 = P * Hout;
     const float *w0 = params[0], *b0 = params[1];
     const int32_t *idxs[2] = {stm, nstm};
+    if (d->ft_factoriser > 0) w0 = A->weff = factorised_weights(d, params);
 
     A->hid = (float *)malloc(sizeof(float) * (size_t)B * K0);
     for (int p = 0; p < P; p++) {
@@ -260,14 +280,42 @@ static float net_forward_impl(const orc_net_desc *d, int B, const float *const *
                 a[(size_t)b * out + o] = z;
             }
         }
+        if (d->dense_dual[k] || d->dense_skip[k]) {
+            /* skip neurons are sliced off first (slice_rows, test2.rs:54-56); the rest may be widened to
+             * concat(x, x*x) (test2.rs:58) and is then activated */
+            const int m = out - d->dense_skip[k], wd = dense_width(d, k);
+            float *act = (float *)malloc(sizeof(float) * (size_t)B * wd);
+            for (int b = 0; b < B; b++)
+                for (int i = 0; i < m; i++) {
+                    float v = a[(size_t)b * out + i];
+                    act[(size_t)b * wd + i] = v;
+                    if (d->dense_dual[k]) act[(size_t)b * wd + m + i] = v * v;
+                }
+            orc_act_fwd(d->dense_act[k], act, act, (size_t)B * wd);
+            A->z[k] = a;
+            A->a[k] = act;
+            x = act;
+            in = wd;
+            continue;
+        }
         orc_act_fwd(d->dense_act[k], a, a, (size_t)B * out);
         A->a[k] = a;
         x = a;
         in = out;
     }
 
+    /* net output: last layer + every skip neuron (`out + skip_neuron`, test2.rs:64) */
+    const int L = d->n_dense, out_last = dense_width(d, L - 1);
+    A->y = (float *)malloc(sizeof(float) * (size_t)B * out_last);
+    for (size_t i = 0; i < (size_t)B * out_last; i++) A->y[i] = A->a[L - 1][i];
+    for (int k = 0; k < L - 1; k++)
+        for (int b = 0; b < B && d->dense_skip[k]; b++)
+            for (int j = 0; j < d->dense_skip[k]; j++)
+                A->y[(size_t)b * out_last + j] =
+                    A->y[(size_t)b * out_last + j] + A->z[k][(size_t)b * d->dense_out[k] + d->dense_out[k] - d->dense_skip[k] + j];
+
     /* a11: loss = sum_b w_b (sigmoid(y_b) - t_b)^2, value/builder.rs:137-142 */
-    const float *y = A->a[d->n_dense - 1];
+    const float *y = A->y;
     A->sig = (float *)malloc(sizeof(float) * (size_t)B);
     float loss = 0.0f;
     for (int b = 0; b < B; b++) {
@@ -285,7 +333,9 @@ static float net_forward_impl(const orc_net_desc *d, int B, const float *const *
 static void acts_free(const orc_net_desc *d, orc_acts *A) {
     for (int p = 0; p < d->perspectives; p++) free(A->c[p]);
     free(A->hid);
-    for (int k = 0; k < d->n_dense; k++) free(A->a[k]);
+    for (int k = 0; k < d->n_dense; k++) free(A->a[k]), free(A->z[k]);
+    free(A->y);
+    free(A->weff);
     free(A->sig);
 }
 
@@ -312,8 +362,9 @@ float orc_net_forward_backward(const orc_net_desc *d, int B, const float *const 
 
     /* seed dL = 1 (definition.rs:101); d(sum) = broadcast; squared_error diff*diff -> g*diff + g*diff
      * (binary.rs:101-123); sigmoid' = o * (1 - o) (dfo.rs:114-118) */
-    int out_last = d->dense_out[d->n_dense - 1];
+    int out_last = dense_width(d, d->n_dense - 1);
     float *gz = (float *)malloc(sizeof(float) * (size_t)B * out_last); /* grad wrt activated output of last layer */
+    float *gy = (float *)malloc(sizeof(float) * (size_t)B * out_last); /* grad wrt the net output (skip neurons get it too) */
     for (int b = 0; b < B; b++) {
         float s = A.sig[b];
         float g = d->use_entry_weights ? entry_weights[b] : 1.0f;
@@ -321,6 +372,7 @@ float orc_net_forward_backward(const orc_net_desc *d, int B, const float *const 
         float dd = g * diff + g * diff;
         gz[b] = dd * (s * (1.0f + (-1.0f * s)));
     }
+    memcpy(gy, gz, sizeof(float) * (size_t)B * out_last);
 
     for (int k = d->n_dense - 1; k >= 0; k--) {
         const int out = d->dense_out[k];
@@ -329,8 +381,29 @@ float orc_net_forward_backward(const orc_net_desc *d, int B, const float *const 
         const float *w = params[2 + 2 * k];
         float *dw = grads[2 + 2 * k], *db = grads[3 + 2 * k];
         const float *x = (k == 0) ? A.hid : A.a[k - 1];
-        /* activation backward from output */
-        orc_act_bwd(d->dense_act[k], A.a[k], gz, gz, (size_t)B * out);
+        if (d->dense_dual[k] || d->dense_skip[k]) {
+            /* activation backward on the widened vector, then Concat/Slice backward (pad.rs, slice.rs) and Mul backward
+             * with both operands = x: contributions arrive in reverse creation order: concat slice, then g*x twice */
+            const int m = out - d->dense_skip[k], wd = dense_width(d, k);
+            orc_act_bwd(d->dense_act[k], A.a[k], gz, gz, (size_t)B * wd);
+            float *gzz = (float *)malloc(sizeof(float) * (size_t)B * out);
+            for (int b = 0; b < B; b++) {
+                for (int i = 0; i < m; i++) {
+                    float g1 = gz[(size_t)b * wd + i];
+                    if (d->dense_dual[k]) {
+                        float g2 = gz[(size_t)b * wd + m + i], xv = A.z[k][(size_t)b * out + i];
+                        g1 = (g1 + g2 * xv) + g2 * xv;
+                    }
+                    gzz[(size_t)b * out + i] = g1;
+                }
+                for (int j = 0; j < d->dense_skip[k]; j++) gzz[(size_t)b * out + m + j] = gy[(size_t)b * out_last + j];
+            }
+            free(gz);
+            gz = gzz;
+        } else {
+            /* activation backward from output */
+            orc_act_bwd(d->dense_act[k], A.a[k], gz, gz, (size_t)B * out);
+        }
         /* SelectPad puts zeros in all other bucket rows (select.rs:93-110); adding exact zeros
          * to dW/db/dX changes nothing, so only the selected rows are visited. Batch order is
          * ascending, as in Matmul::evaluate's ni loop over the batch-contracted operand. */
@@ -355,6 +428,7 @@ float orc_net_forward_backward(const orc_net_desc *d, int B, const float *const 
         free(gz);
         gz = gx;
     }
+    free(gy);
 
     /* gz is now d(hidden) [B][K0]; FT backward */
     float *gp[2] = {NULL, NULL};
@@ -387,6 +461,18 @@ float orc_net_forward_backward(const orc_net_desc *d, int B, const float *const 
         int rows[2] = {H, H}, offs[2] = {0, 0};
         const float *gc[2] = {gp[0], gp[1]};
         orc_sparse_matmul_bwd_multi(P, gc, idxs, grads[0], B, rows, F, H, offs, N, 1);
+    }
+    if (d->ft_factoriser > 0) {
+        /* l0w + repeat(l0f): Add passes the gradient to both; Broadcast(Cols) backward is the sum over the
+         * repeats (broadcast.rs:121-124, reduce.rs:96-120), taken here in ascending repeat order */
+        const int Fc = F / d->ft_factoriser;
+        float *dwf = grads[2 + 2 * d->n_dense];
+        for (int j = 0; j < Fc; j++)
+            for (int r = 0; r < H; r++) {
+                float sacc = 0.0f;
+                for (int rep = 0; rep < d->ft_factoriser; rep++) sacc = sacc + grads[0][((size_t)rep * Fc + j) * H + r];
+                dwf[(size_t)j * H + r] = sacc;
+            }
     }
     for (int p = 0; p < P; p++) free(gp[p]);
     free(gz);
@@ -663,7 +749,7 @@ void orc_net_init(const orc_net_desc *d, uint64_t seed, int ft_eff, float *const
     int nt = orc_net_num_tensors(d);
     for (int t = 0; t < nt; t++) {
         size_t n = orc_net_tensor_size(d, t);
-        if (t & 1) { /* bias: InitSettings::Zeroed consumes no RNG, weights.rs:64 */
+        if ((t & 1) || (d->ft_factoriser > 0 && t == nt - 1)) { /* biases and l0f: InitSettings::Zeroed consumes no RNG, weights.rs:64 */
             memset(params[t], 0, n * sizeof(float));
             continue;
         }

@@ -95,13 +95,20 @@ typedef struct {
     int dense_act[ORC_MAX_DENSE];      /* activation after layer k        */
     int dense_bucketed[ORC_MAX_DENSE]; /* 1: rows = out*num_buckets + select */
     int use_entry_weights;             /* value/builder.rs:137-140 */
+    /* --- extensions used by examples/tests/test2.rs and examples/progression/3_input_buckets.rs --- */
+    int ft_factoriser;                 /* NB > 0: W_eff = l0w + l0f.repeat(NB), l0f is [ft_out x num_inputs/NB]
+                                          (3_input_buckets.rs:62-67; Broadcast(Cols), operations/linear.rs:37-55) */
+    int dense_dual[ORC_MAX_DENSE];     /* 1: x -> concat(x, x*x) before the activation (test2.rs:58-59)        */
+    int dense_skip[ORC_MAX_DENSE];     /* s: the last s outputs of layer k bypass the rest of the net and are added
+                                          to the final output (slice_rows + `out + skip_neuron`, test2.rs:54-64) */
 } orc_net_desc;
 
-/* number of weight tensors: l0w,l0b,l1w,l1b,... */
+/* number of weight tensors: l0w,l0b,l1w,l1b,... and, last, l0f when ft_factoriser > 0 */
 int orc_net_num_tensors(const orc_net_desc *d);
-/* element count of tensor t (order l0w,l0b,l1w,l1b,...) */
+/* element count of tensor t (order l0w,l0b,l1w,l1b,...[,l0f]) */
 size_t orc_net_tensor_size(const orc_net_desc *d, int t);
-/* input width of dense layer k */
+/* input width of dense layer k: the concat of the perspectives for k = 0, else
+ * (dense_out[k-1] - dense_skip[k-1]) * (dense_dual[k-1] ? 2 : 1) */
 int orc_net_dense_in(const orc_net_desc *d, int k);
 
 /* One fwd+bwd pass (Appendix A of SURVEY.md). params/grads are arrays of
