@@ -10,8 +10,8 @@ import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_hbm"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/hbm_traffic.json"
-KERNELS = ["ft_fwd_lds", "ft_index_kernel", "ft_bwd_lds", "ft_bwd_merge", "dense_fwd_small", "dense_bwd_small",
-           "sum_partials4_kernel", "adamw_kernel"]
+KERNELS = ["ft_fwd_lds", "ft_index_kernel", "ft_bwd_lds", "ft_bwd_merge", "head_finish_kernel", "dense_fwd_small",
+           "dense_bwd_small_light", "dense_bwd_small", "sum_partials_seq4_kernel", "sum_partials4_kernel", "adamw_kernel"]
 
 
 def avg(path, counter):
@@ -30,7 +30,7 @@ f, w = avg(f"{src}/FETCH_SIZE.csv", "FETCH_SIZE"), avg(f"{src}/WRITE_SIZE.csv", 
 out = {"_comment": __doc__.strip().replace("\n", " ")}
 for k in KERNELS:
     if k in f and k in w:
-        name = k.replace("sum_partials4_kernel", "sum_partials_kernel")
+        name = k
         out[name] = {"FETCH_SIZE_KB": round(f[k], 1), "WRITE_SIZE_KB": round(w[k], 1),
                      "hbm_bytes_per_launch": round((2 * f[k] + w[k]) * 1024, 1)}
 json.dump(out, open(dst, "w"), indent=1)
