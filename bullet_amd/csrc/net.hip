@@ -4,7 +4,10 @@
 // (FT fwd x perspectives -> dense stack with bucket select -> sigmoid-MSE -> dense bwd -> FT bwd -> AdamW).
 // All buffers are allocated once in bt_net_create (Function::prealloc, function.rs:180-196);
 // a step only enqueues kernels on the caller's stream -- no host sync, no allocation.
+#include <sys/stat.h>
+
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -493,6 +496,47 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
                                                 n->grads + n->t_off[1], n->ft_ws, n->ft_ws_bytes))
         return rc;
     return factor_reduce();
+}
+
+// save_to_checkpoint, crates/bullet_lib/src/value/save.rs:24-43 (directories are created if missing, errors of the
+// raw / quantised writers are reported but, unlike the reference, also returned)
+int bt_net_save_checkpoint(bt_net *n, void *stream, const bt_saved_format *fmt, int n_fmt, const char *dir) {
+    BT_REQUIRE(n && dir, "bt_net_save_checkpoint: null argument");
+    hipStream_t s = bt_stream(stream);
+    std::vector<float> host(n->n_params);
+    const std::string base(dir), opt = base + "/optimiser_state";
+    (void)mkdir(base.c_str(), 0777);
+    (void)mkdir(opt.c_str(), 0777);
+    const struct {
+        const float *dev;
+        const char *file;
+    } parts[3] = {{n->params, "/weights.bin"}, {n->mom, "/momentum.bin"}, {n->vel, "/velocity.bin"}};
+    for (int i = 2; i >= 0; i--) {  // weights last: `host` then holds them for raw.bin / quantised.bin
+        BT_HIP(hipMemcpyAsync(host.data(), parts[i].dev, n->n_params * sizeof(float), hipMemcpyDeviceToHost, s));
+        BT_HIP(hipStreamSynchronize(s));
+        if (int rc = bt_checkpoint_write(&n->d, host.data(), (opt + parts[i].file).c_str())) return rc;
+    }
+    if (int rc = bt_save_raw(&n->d, host.data(), fmt, n_fmt, (base + "/raw.bin").c_str())) return rc;
+    return bt_save_quantised(&n->d, host.data(), fmt, n_fmt, (base + "/quantised.bin").c_str());
+}
+
+// Optimiser::load_from_checkpoint, crates/trainer/src/optimiser.rs:232-236 + adam.rs:309-324
+int bt_net_load_checkpoint(bt_net *n, void *stream, const char *dir) {
+    BT_REQUIRE(n && dir, "bt_net_load_checkpoint: null argument");
+    hipStream_t s = bt_stream(stream);
+    std::vector<float> host(n->n_params);
+    const std::string opt = std::string(dir) + "/optimiser_state";
+    const struct {
+        float *dev;
+        const char *file;
+    } parts[3] = {{n->params, "/weights.bin"}, {n->mom, "/momentum.bin"}, {n->vel, "/velocity.bin"}};
+    for (int i = 0; i < 3; i++) {
+        std::fill(host.begin(), host.end(), 0.0f);
+        if (int rc = bt_checkpoint_read(&n->d, host.data(), (opt + parts[i].file).c_str())) return rc;
+        BT_HIP(hipMemcpyAsync(parts[i].dev, host.data(), n->n_params * sizeof(float), hipMemcpyHostToDevice, s));
+        BT_HIP(hipStreamSynchronize(s));
+    }
+    return BT_OK;
 }
 
 int bt_net_optimiser_step(bt_net *n, void *stream, const float *adj_dev, const float *lr_dev) {

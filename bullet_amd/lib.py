@@ -41,6 +41,40 @@ class NetDesc(C.Structure):
     ]
 
 
+SAVE_TRANSFORM = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_size_t)
+QUANT = {"float": 0, "i8": 1, "i16": 2, "i32": 3}
+
+
+class SavedFormat(C.Structure):
+    _fields_ = [("id", C.c_char_p), ("custom", C.c_void_p), ("custom_len", C.c_size_t), ("quant", C.c_int),
+                ("multiplier", C.c_int), ("round", C.c_int), ("transpose", C.c_int), ("merge_factoriser", C.c_int),
+                ("transform", SAVE_TRANSFORM), ("user", C.c_void_p)]
+
+
+def saved_formats(entries):
+    """entries: list of dicts {id|custom, quant=("i16", 255), round, transpose, merge_factoriser, transform}.
+    Returns (ctypes array, keepalive list)."""
+    arr = (SavedFormat * len(entries))()
+    keep = []
+    for f, e in zip(arr, entries):
+        if "custom" in e:
+            b = C.create_string_buffer(bytes(e["custom"]), len(e["custom"]))
+            keep.append(b)
+            f.custom, f.custom_len = C.cast(b, C.c_void_p), len(e["custom"])
+            continue
+        f.id = e["id"].encode()
+        q = e.get("quant")
+        if q:
+            f.quant, f.multiplier = QUANT[q[0]], int(q[1])
+        f.round, f.transpose = int(e.get("round", False)), int(e.get("transpose", False))
+        f.merge_factoriser = int(e.get("merge_factoriser", False))
+        if e.get("transform"):
+            cb = SAVE_TRANSFORM(e["transform"])
+            keep.append(cb)
+            f.transform = cb
+    return arr, keep
+
+
 class Batch(C.Structure):
     _fields_ = [("batch", C.c_int), ("stm", C.c_void_p), ("nstm", C.c_void_p), ("buckets", C.c_void_p),
                 ("targets", C.c_void_p), ("entry_weights", C.c_void_p)]
@@ -93,6 +127,8 @@ SYMBOLS = [
     "bt_input_init", "bt_input_num_inputs", "bt_input_max_active", "bt_map_batch",
     "bt_net_init_weights_host", "bt_lr_at", "bt_wdl_at", "bt_reader_open", "bt_reader_next", "bt_reader_close",
     "bt_train_run",
+    "bt_net_tensor_name", "bt_net_tensor_shape", "bt_checkpoint_write", "bt_checkpoint_read", "bt_save_quantised",
+    "bt_save_raw", "bt_net_save_checkpoint", "bt_net_load_checkpoint",
 ]
 
 _lib = None
@@ -139,6 +175,15 @@ def load():
     L.bt_net_num_tensors.argtypes = [C.POINTER(NetDesc)]
     L.bt_net_tensor_size.argtypes = [C.POINTER(NetDesc), C.c_int]
     L.bt_net_tensor_offset.argtypes = [C.POINTER(NetDesc), C.c_int]
+    L.bt_net_tensor_name.argtypes = [C.POINTER(NetDesc), C.c_int]
+    L.bt_net_tensor_name.restype = C.c_char_p
+    L.bt_net_tensor_shape.argtypes = [C.POINTER(NetDesc), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.bt_checkpoint_write.argtypes = [C.POINTER(NetDesc), C.c_void_p, C.c_char_p]
+    L.bt_checkpoint_read.argtypes = [C.POINTER(NetDesc), C.c_void_p, C.c_char_p]
+    L.bt_save_quantised.argtypes = [C.POINTER(NetDesc), C.c_void_p, C.POINTER(SavedFormat), C.c_int, C.c_char_p]
+    L.bt_save_raw.argtypes = [C.POINTER(NetDesc), C.c_void_p, C.POINTER(SavedFormat), C.c_int, C.c_char_p]
+    L.bt_net_save_checkpoint.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(SavedFormat), C.c_int, C.c_char_p]
+    L.bt_net_load_checkpoint.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
     L.bt_net_create.argtypes = [C.POINTER(NetDesc), C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
     L.bt_net_destroy.argtypes = [C.c_void_p]
     L.bt_net_set_adamw.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 5
@@ -273,6 +318,18 @@ class Net:
         host = np.zeros(self.n_flat, dtype=np.float32)
         check(self.L.bt_net_init_weights_host(C.byref(self.desc), seed, ft_effective_inputs, host.ctypes.data))
         self.params.copy_(torch.from_numpy(host).to(self.params.device))
+
+    def save_checkpoint(self, path, entries, stream=None):
+        """save_to_checkpoint (value/save.rs:24-43)"""
+        import torch
+        arr, keep = saved_formats(entries)
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        check(self.L.bt_net_save_checkpoint(self.h, s, arr, len(entries), str(path).encode()))
+
+    def load_checkpoint(self, path, stream=None):
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        check(self.L.bt_net_load_checkpoint(self.h, s, str(path).encode()))
 
     def train(self, input_desc, paths, batch_size, batches_per_superbatch, end_superbatch, lr, wdl, eval_scale=400.0,
               start_superbatch=1, out_buckets=1, threads=4, log_rate=0, win_rate_model=False, on_batch=None,

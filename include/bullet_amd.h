@@ -342,6 +342,56 @@ typedef void (*bt_superbatch_callback)(void *user, int superbatch, float running
 int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_train_config *cfg, const char *const *paths,
                  int n_paths, bt_batch_callback on_batch, bt_superbatch_callback on_superbatch, void *user);
 
+/* ------------------------------------------------------------------------------------------
+ * 6. Checkpoints and saved network files (host code)
+ *    (crates/trainer/src/model/weights.rs:95-177,183-334,404-467, crates/trainer/src/optimiser.rs:218-236,
+ *     crates/trainer/src/optimiser/adam.rs:300-324, crates/bullet_lib/src/value/save.rs:24-85)
+ * ------------------------------------------------------------------------------------------ */
+
+/* Weight ids of the net family in flat-buffer order: "l0w","l0b","l1w","l1b",...[,"l0f"] (builder names,
+ * crates/compiler/src/model/builder.rs:120-131) and their [rows x cols] shapes (column-major). */
+const char *bt_net_tensor_name(const bt_net_desc *desc, int tensor);
+int bt_net_tensor_shape(const bt_net_desc *desc, int tensor, int *rows, int *cols);
+
+/* weights.bin / momentum.bin / velocity.bin: a stream of records `id '\n' | u64 LE count | f32 LE values`
+ * (weights.rs:404-431), one per weight, in the reference's BTreeMap order = ascending id ("l0b","l0f","l0w",...).
+ * flat_host is a bt_net_param_count() buffer. Reading accepts any record order; an unknown id or a size
+ * mismatch is an error ("No weight with ID found!", "Invalid buffer size!", weights.rs:119-127). */
+int bt_checkpoint_write(const bt_net_desc *desc, const float *flat_host, const char *path);
+int bt_checkpoint_read(const bt_net_desc *desc, float *flat_host, const char *path);
+
+/* SavedFormat (weights.rs:183-275). One entry of the network file: either custom bytes, or the weight `id`,
+ * transformed, then quantised. Transforms run in this order: merge_factoriser (adds l0f.repeat(NB): the closure of
+ * examples/progression/3_input_buckets.rs:47-51), the optional callback, transpose (weights.rs:262-275). */
+enum { BT_QUANT_FLOAT = 0, BT_QUANT_I8 = 1, BT_QUANT_I16 = 2, BT_QUANT_I32 = 3 };
+typedef int (*bt_save_transform)(void *user, const char *id, float *values, size_t count); /* in place; 0 = ok */
+typedef struct {
+    const char *id;      /* weight id; NULL for a custom entry */
+    const void *custom;  /* SavedFormat::custom bytes (header, padding ...) */
+    size_t custom_len;
+    int quant;           /* BT_QUANT_* (QuantTarget, weights.rs:277-286) */
+    int multiplier;      /* q in round_or_trunc(q * x) computed in f64 (weights.rs:288-331) */
+    int round;           /* SavedFormat::round: round half away from zero instead of truncating */
+    int transpose;
+    int merge_factoriser;
+    bt_save_transform transform;
+    void *user;
+} bt_saved_format;
+
+/* quantised.bin: entries back to back, padded to a multiple of 64 bytes with the characters of "bullet"
+ * (weights.rs:160-177). A value that does not fit the target type fails with
+ * "Failed quantisation from f32 to i16!" and writes nothing. raw.bin: the untransformed f32 weights of every
+ * entry that has an id (save.rs:46-68). */
+int bt_save_quantised(const bt_net_desc *desc, const float *flat_host, const bt_saved_format *fmt, int n_fmt,
+                      const char *path);
+int bt_save_raw(const bt_net_desc *desc, const float *flat_host, const bt_saved_format *fmt, int n_fmt, const char *path);
+
+/* save_to_checkpoint (save.rs:24-43): dir/optimiser_state/{weights,momentum,velocity}.bin, dir/raw.bin,
+ * dir/quantised.bin from the device state of `net` (synchronises `stream`). load = Optimiser::load_from_checkpoint
+ * (optimiser.rs:232-236): weights, momentum and velocity back onto the device. */
+int bt_net_save_checkpoint(bt_net *net, void *stream, const bt_saved_format *fmt, int n_fmt, const char *dir);
+int bt_net_load_checkpoint(bt_net *net, void *stream, const char *dir);
+
 #ifdef __cplusplus
 }
 #endif

@@ -258,3 +258,40 @@ def test_train_run_resume_matches_continuous_run(tmp_path):
     # AdamW moments live in the net, so the resumed run is the same computation: bit-identical
     assert [r[1] for r in full] == [r[1] for r in split]
     assert torch.equal(w_full, w_split)
+
+
+def test_checkpoint_save_load_round_trip_on_device(tmp_path):
+    """save_to_checkpoint / load_from_checkpoint (value/save.rs:24-43, optimiser.rs:218-236): a net restored from the
+    checkpoint directory continues bit-identically."""
+    cfg = NETS["factoriser_single_layer"][0]
+    kind, layout, fact = NETS["factoriser_single_layer"][1]
+    batches = fixture_batches(kind, layout, fact, 8, 0.5, 3, batch=2000)
+    dn = lib.make_net_desc(**cfg)
+    adj, lr = torch.tensor([1.0 / 2000], device="cuda"), torch.tensor([1e-3], device="cuda")
+
+    def step(net, i):
+        stm, ntm, bk, tg, w = batches[i]
+        net.forward_backward(net.make_batch(gu.dev(stm), gu.dev(ntm), gu.dev(bk), gu.dev(tg), gu.dev(w)))
+        net.optimiser_step(adj, lr)
+        torch.cuda.synchronize()
+        return net.loss.item()
+
+    a = lib.Net(dn, 2000)
+    a.init_weights()
+    step(a, 0), step(a, 1)
+    entries = [dict(id="l0w", merge_factoriser=True, round=True, quant=("i16", 255)), dict(id="l0b", round=True, quant=("i16", 255)),
+               dict(id="l1w", round=True, quant=("i16", 64), transpose=True), dict(id="l1b", round=True, quant=("i16", 255 * 64))]
+    a.save_checkpoint(tmp_path / "ckpt", entries)
+    for f in ["optimiser_state/weights.bin", "optimiser_state/momentum.bin", "optimiser_state/velocity.bin", "raw.bin",
+              "quantised.bin"]:
+        assert (tmp_path / "ckpt" / f).stat().st_size > 0
+    assert (tmp_path / "ckpt" / "quantised.bin").stat().st_size % 64 == 0
+    b = lib.Net(dn, 2000)
+    b.load_checkpoint(tmp_path / "ckpt")
+    for name in ["params"]:
+        for x, y in zip(a.get_tensors(a.params), b.get_tensors(b.params)):
+            assert np.array_equal(x, y)
+    for x, y in zip(a.state_view("momentum"), b.state_view("momentum")):
+        assert np.array_equal(x, y)
+    assert step(a, 2) == step(b, 2)
+    a.close(), b.close()
