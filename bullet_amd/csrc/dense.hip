@@ -303,7 +303,7 @@ __global__ __launch_bounds__(DF_THREADS) void dense_fwd_small(const float *__res
                                                               const int32_t *__restrict__ bucket,
                                                               float *__restrict__ y, bt_dense_desc d, int pos_per_wg,
                                                               LossArgs la) {
-    extern __shared__ float wt[];  // [rows][in + 4]
+    extern __shared__ __align__(16) float wt[];  // [rows][in + 4] (16-B aligned: ds_read_b128)
     __shared__ float wave_loss[DF_THREADS / 64];
     float loss_acc = 0.0f;
     const int rows = d.out * d.buckets;
@@ -581,6 +581,289 @@ __global__ __launch_bounds__(DBS_CT) __attribute__((amdgpu_waves_per_eu(5, 5))) 
 }
 
 
+// ------------------------------------------------------------------ mid-size bucketed layers
+// Layers with a few outputs per bucket and a wide input (HalfKA nets: 1024 -> 16 x 8 buckets). The reference runs
+// a GEMM over ALL bucket rows and discards 7/8 of it (matmul.rs:62-93 + select.rs:12-26); here only the selected
+// bucket is computed. One bucket's rows (out x in, 64 KiB) fit in LDS, all buckets do not, so a workgroup takes a
+// chunk of positions and goes through the buckets present in it: load that bucket's rows transposed, then one wave
+// per matching position. Positions keep their ascending order inside a bucket => fixed summation orders.
+constexpr int DM_THREADS = 1024;
+constexpr int DM_CHUNK = 64;    // positions per workgroup, forward / dX
+constexpr int DM_RANGE = 128;   // positions per workgroup, dW
+constexpr int DM_OH = 8;        // output rows per workgroup, dW
+
+bool dense_mid_ok(const bt_dense_desc *d) {
+    return d->out > 1 && d->out <= 32 && d->buckets <= 32 && d->in % 256 == 0 && d->in / 256 <= 8 &&
+           (size_t)d->out * (d->in + 4) * sizeof(float) <= 96 * 1024;
+}
+
+// positions of the chunk whose bucket is bk, ascending, into s_list; returns their number (all threads)
+__device__ __forceinline__ int dm_bucket_list(const uint8_t *s_bk, int npos, int bk, int *s_list, int *s_wcnt) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    unsigned long long m = 0;
+    bool flag = false;
+    if (t < DM_RANGE) {  // whole waves: DM_RANGE is a multiple of 64
+        flag = t < npos && s_bk[t] == bk;
+        m = __ballot(flag);
+        if (lane == 0) s_wcnt[wave] = __popcll(m);
+    }
+    __syncthreads();
+    if (flag) {
+        int base = 0;
+        for (int w2 = 0; w2 < wave; w2++) base += s_wcnt[w2];
+        s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = t;
+    }
+    int cnt = 0;
+    for (int w2 = 0; w2 < DM_RANGE / 64; w2++) cnt += s_wcnt[w2];
+    __syncthreads();
+    return cnt;
+}
+
+__global__ __launch_bounds__(256) void dense_gz_kernel(const float *__restrict__ y, const float *__restrict__ grad_y,
+                                                       float *__restrict__ gz, size_t n, int act) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) gz[t] = grad_y[t] * bt_act_deriv(act, y[t]);
+}
+
+// DX = false: y[b][o] = f(W[bucket][o] . x[b] + bias);  DX = true: gx[b][i] = sum_o W[bucket][o][i] * gz[b][o]
+template <int NX, bool DX>
+__global__ __launch_bounds__(DM_THREADS) void dense_mid_kernel(const float *__restrict__ w, const float *__restrict__ bias,
+                                                               const float *__restrict__ src,
+                                                               const int32_t *__restrict__ bucket,
+                                                               float *__restrict__ dst, bt_dense_desc d) {
+    extern __shared__ __align__(16) float wt[];  // [out][in + 4]: the current bucket's rows, transposed (16-B aligned)
+    __shared__ uint8_t s_bk[DM_RANGE];
+    __shared__ int s_list[DM_RANGE], s_wcnt[DM_RANGE / 64];
+    __shared__ unsigned s_mask;
+    const int rows = d.out * d.buckets, ldw = d.in + 4;
+    const int b0 = blockIdx.x * DM_CHUNK, npos = min(DM_CHUNK, d.batch - b0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_mask = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < npos) {
+        const int bk = (d.buckets > 1) ? bucket[b0 + threadIdx.x] : 0;
+        s_bk[threadIdx.x] = (uint8_t)bk;
+        atomicOr(&s_mask, 1u << bk);
+    }
+    __syncthreads();
+    const unsigned mask = s_mask;
+    for (int bk = 0; bk < d.buckets; bk++) {
+        if (!((mask >> bk) & 1u)) continue;
+        const int cnt = dm_bucket_list(s_bk, npos, bk, s_list, s_wcnt);  // (barriers inside: wt readers are done)
+        for (int q = threadIdx.x; q < d.out * d.in; q += DM_THREADS) {
+            const int i = q / d.out, r = q - i * d.out;
+            wt[r * ldw + i] = w[(size_t)rows * i + bk * d.out + r];
+        }
+        __syncthreads();
+        // per-output scalars live in lanes 0..out-1 (one load per round / position) and are read with v_readlane, so
+        // the output loop has no dependent global load
+        const float bias_l = (!DX && lane < d.out) ? bias[bk * d.out + lane] : 0.0f;
+        for (int j = wave; j < cnt; j += DM_THREADS / 64) {
+            const int b = b0 + __builtin_amdgcn_readfirstlane(s_list[j]);
+            if constexpr (!DX) {
+                const float4 *xb = reinterpret_cast<const float4 *>(src + (size_t)b * d.in);
+                float4 xv[NX];
+#pragma unroll
+                for (int c = 0; c < NX; c++) xv[c] = xb[c * 64 + lane];
+                float res = 0.0f;  // lane o ends up with output o
+                for (int o = 0; o < d.out; o++) {
+                    const float4 *wr = reinterpret_cast<const float4 *>(wt + o * ldw);
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < NX; c++) {
+                        const float4 w4 = wr[c * 64 + lane];
+                        acc += xv[c].x * w4.x, acc += xv[c].y * w4.y, acc += xv[c].z * w4.z, acc += xv[c].w * w4.w;
+                    }
+                    const float sum = wave_sum(acc);
+                    if (lane == o) res = bt_act_fwd(d.act, sum + bias_l);
+                }
+                if (lane < d.out) dst[(size_t)b * d.out + lane] = res;
+            } else {
+                const float g_l = (lane < d.out) ? src[(size_t)b * d.out + lane] : 0.0f;
+                float4 acc[NX];
+#pragma unroll
+                for (int c = 0; c < NX; c++) acc[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                for (int o = 0; o < d.out; o++) {
+                    const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_l), o));
+                    const float4 *wr = reinterpret_cast<const float4 *>(wt + o * ldw);
+#pragma unroll
+                    for (int c = 0; c < NX; c++) {
+                        const float4 w4 = wr[c * 64 + lane];
+                        acc[c].x += w4.x * g, acc[c].y += w4.y * g, acc[c].z += w4.z * g, acc[c].w += w4.w * g;
+                    }
+                }
+                float4 *gx = reinterpret_cast<float4 *>(dst + (size_t)b * d.in);
+#pragma unroll
+                for (int c = 0; c < NX; c++) gx[c * 64 + lane] = acc[c];
+            }
+        }
+    }
+}
+
+// dW / dbias partials of one position range, DM_OH output rows per workgroup: thread i owns input column i (and
+// i + 1024) for those rows in registers; gz values are wave-uniform. Partial layout [range][row][in].
+__global__ __launch_bounds__(DM_THREADS) void dense_mid_dw_kernel(const float *__restrict__ x,
+                                                                  const int32_t *__restrict__ bucket,
+                                                                  const float *__restrict__ gz, float *__restrict__ part_w,
+                                                                  float *__restrict__ part_b, bt_dense_desc d) {
+    __shared__ uint8_t s_bk[DM_RANGE];
+    __shared__ int s_list[DM_RANGE], s_wcnt[DM_RANGE / 64];
+    const int rows = d.out * d.buckets;
+    const int b0 = blockIdx.x * DM_RANGE, npos = min(DM_RANGE, d.batch - b0);
+    const int o0 = blockIdx.y * DM_OH, noh = min(DM_OH, d.out - o0);
+    const int i0 = threadIdx.x, i1 = threadIdx.x + DM_THREADS;
+    const bool c0 = i0 < d.in, c1 = i1 < d.in;
+    if ((int)threadIdx.x < npos) s_bk[threadIdx.x] = (uint8_t)((d.buckets > 1) ? bucket[b0 + threadIdx.x] : 0);
+    __syncthreads();
+    float *pw = part_w + (size_t)blockIdx.x * rows * d.in;
+    for (int bk = 0; bk < d.buckets; bk++) {
+        const int cnt = dm_bucket_list(s_bk, npos, bk, s_list, s_wcnt);
+        float a0[DM_OH], a1[DM_OH], ab[DM_OH];
+#pragma unroll
+        for (int o = 0; o < DM_OH; o++) a0[o] = a1[o] = ab[o] = 0.0f;
+        constexpr int U = 8;
+        // lanes 0..DM_OH-1 of every wave hold the position's gz values (read back with v_readlane); two batches of
+        // U positions are in flight
+        auto load = [&](int j0, float(&x0)[U], float(&x1)[U], float(&gl)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int b = b0 + __builtin_amdgcn_readfirstlane(s_list[min(j0 + u, max(cnt - 1, 0))]);
+                x0[u] = c0 ? x[(size_t)b * d.in + i0] : 0.0f;
+                x1[u] = c1 ? x[(size_t)b * d.in + i1] : 0.0f;
+                const int lo = threadIdx.x & 63;
+                gl[u] = (lo < noh) ? gz[(size_t)b * d.out + o0 + lo] : 0.0f;
+            }
+        };
+        auto consume = [&](int j0, const float(&x0)[U], const float(&x1)[U], const float(&gl)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (j0 + u < cnt) {
+#pragma unroll
+                    for (int o = 0; o < DM_OH; o++) {
+                        const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl[u]), o));
+                        a0[o] += g * x0[u], a1[o] += g * x1[u], ab[o] += g;
+                    }
+                }
+            }
+        };
+        if (cnt > 0) {
+            float xa0[U], xa1[U], ga[U], xb0[U], xb1[U], gb[U];
+            load(0, xa0, xa1, ga);
+            for (int j0 = 0; j0 < cnt; j0 += 2 * U) {
+                load(j0 + U, xb0, xb1, gb);
+                consume(j0, xa0, xa1, ga);
+                load(j0 + 2 * U, xa0, xa1, ga);
+                consume(j0 + U, xb0, xb1, gb);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < DM_OH; o++) {
+            if (o < noh) {
+                float *pr = pw + (size_t)(bk * d.out + o0 + o) * d.in;  // zeros for buckets absent from the range
+                if (c0) pr[i0] = a0[o];
+                if (c1) pr[i1] = a1[o];
+                if (threadIdx.x == 0) part_b[(size_t)blockIdx.x * rows + bk * d.out + o0 + o] = ab[o];
+            }
+        }
+    }
+}
+
+// dw[row + rows*i] = sum over ranges of part[range][row][i] (ascending), i.e. back to W's column-major layout
+__global__ __launch_bounds__(256) void sum_partials_t_kernel(const float *__restrict__ part, int nparts, int rows, int in,
+                                                             float *__restrict__ dw) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)rows * in) return;
+    const int r = (int)(t / in), i = (int)(t - (size_t)r * in);
+    const size_t stride = (size_t)rows * in;
+    float s = 0.0f;
+    int p = 0;
+    for (; p + 8 <= nparts; p += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = part[(size_t)(p + u) * stride + t];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; p < nparts; p++) s += part[(size_t)p * stride + t];
+    dw[(size_t)rows * i + r] = s;
+}
+
+// ------------------------------------------------------------------ tiny layers (HalfKA nets: 16 -> 32 x 8, 32 -> 1 x 8)
+// A few hundred weights per bucket: one thread per output element, the weights come from L1.
+bool dense_tiny_ok(const bt_dense_desc *d) {
+    return d->in <= 64 && d->out <= 64 && d->out * d->in <= 1024 && d->buckets <= 16;
+}
+
+__global__ __launch_bounds__(256) void dense_tiny_fwd_kernel(const float *__restrict__ w, const float *__restrict__ bias,
+                                                             const float *__restrict__ x,
+                                                             const int32_t *__restrict__ bucket, float *__restrict__ y,
+                                                             bt_dense_desc d) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)d.batch * d.out) return;
+    const int b = (int)(t / d.out), o = (int)(t - (size_t)b * d.out);
+    const int rows = d.out * d.buckets, row = ((d.buckets > 1) ? bucket[b] * d.out : 0) + o;
+    const float *xb = x + (size_t)b * d.in;
+    float z = 0.0f;
+    for (int i = 0; i < d.in; i++) z += w[(size_t)rows * i + row] * xb[i];  // ascending i, like the oracle
+    y[t] = bt_act_fwd(d.act, z + bias[row]);
+}
+
+__global__ __launch_bounds__(256) void dense_tiny_dx_kernel(const float *__restrict__ w, const float *__restrict__ gz,
+                                                            const int32_t *__restrict__ bucket,
+                                                            float *__restrict__ grad_x, bt_dense_desc d) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)d.batch * d.in) return;
+    const int b = (int)(t / d.in), i = (int)(t - (size_t)b * d.in);
+    const int rows = d.out * d.buckets, base = (d.buckets > 1) ? bucket[b] * d.out : 0;
+    const float *wc = w + (size_t)rows * i + base, *g = gz + (size_t)b * d.out;
+    float s = 0.0f;
+    for (int o = 0; o < d.out; o++) s += wc[o] * g[o];
+    grad_x[t] = s;
+}
+
+// thread (o, i) owns dW[bucket*out + o][i] for every bucket in registers; the position's bucket is wave-uniform, so
+// the select is a scalar branch. Partial layout [range][row][in], dbias partial from the i == 0 threads.
+template <int NB>
+__global__ __launch_bounds__(1024) void dense_tiny_dw_kernel(const float *__restrict__ x,
+                                                             const int32_t *__restrict__ bucket,
+                                                             const float *__restrict__ gz, float *__restrict__ part_w,
+                                                             float *__restrict__ part_b, bt_dense_desc d) {
+    __shared__ int s_bk[DM_RANGE];
+    const int rows = d.out * d.buckets;
+    const int b0 = blockIdx.x * DM_RANGE, npos = min(DM_RANGE, d.batch - b0);
+    const int o = threadIdx.x / d.in, i = threadIdx.x - o * d.in;  // blockDim.x == out * in
+    if ((int)threadIdx.x < npos) s_bk[threadIdx.x] = (d.buckets > 1) ? bucket[b0 + threadIdx.x] : 0;
+    __syncthreads();
+    float acc[NB], ab[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) acc[k] = ab[k] = 0.0f;
+    constexpr int U = 8;
+    for (int p0 = 0; p0 < npos; p0 += U) {
+        float xv[U], gv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int b = b0 + min(p0 + u, npos - 1);
+            xv[u] = x[(size_t)b * d.in + i], gv[u] = gz[(size_t)b * d.out + o];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (p0 + u < npos) {
+                const int bk = __builtin_amdgcn_readfirstlane(s_bk[p0 + u]);
+#pragma unroll
+                for (int k = 0; k < NB; k++)
+                    if (k == bk) acc[k] += gv[u] * xv[u], ab[k] += gv[u];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        if (k < d.buckets) {
+            part_w[(size_t)blockIdx.x * rows * d.in + (size_t)(k * d.out + o) * d.in + i] = acc[k];
+            if (i == 0) part_b[(size_t)blockIdx.x * rows + k * d.out + o] = ab[k];
+        }
+    }
+}
+
 bool dense_fwd_small_ok(const bt_dense_desc *d) {
     const int rows = d->out * d->buckets;
     return d->in % 256 == 0 && d->in / 256 <= 8 && (size_t)rows * (d->in + 4) * sizeof(float) <= 96 * 1024;
@@ -666,6 +949,29 @@ int dense_bwd_small_launch(hipStream_t s, const bt_dense_desc *d, const float *w
     return BT_OK;
 }
 
+// forward (dx = false: src = x, dst = y) or dX (dx = true: src = gz, dst = grad_x) of a mid-size bucketed layer
+int dense_mid_launch(hipStream_t s, const bt_dense_desc *d, const float *w, const float *bias, const float *src,
+                     const int32_t *bucket, float *dst, bool dx) {
+    const size_t lds = (size_t)d->out * (d->in + 4) * sizeof(float);
+    dim3 grid(bt_div_up(d->batch, DM_CHUNK)), block(DM_THREADS);
+#define DML(NX)                                                                                                      \
+    case NX:                                                                                                         \
+        if (dx) {                                                                                                    \
+            if (int rc = dense_set_lds(dense_mid_kernel<NX, true>, lds)) return rc;                                  \
+            BT_LAUNCH(BTK_DENSE_BWD_DX, s, (dense_mid_kernel<NX, true>), grid, block, lds, w, bias, src, bucket, dst, *d); \
+        } else {                                                                                                     \
+            if (int rc = dense_set_lds(dense_mid_kernel<NX, false>, lds)) return rc;                                 \
+            BT_LAUNCH(BTK_DENSE_FWD, s, (dense_mid_kernel<NX, false>), grid, block, lds, w, bias, src, bucket, dst, *d);  \
+        }                                                                                                            \
+        break;
+    switch (d->in / 256) {
+        DML(1) DML(2) DML(3) DML(4) DML(5) DML(6) DML(7) DML(8)
+    }
+#undef DML
+    BT_LAUNCH_CHECK();
+    return BT_OK;
+}
+
 int dense_validate(const bt_dense_desc *d, const char *who) {
     BT_REQUIRE(d, "%s: null descriptor", who);
     BT_REQUIRE(d->batch > 0 && d->in > 0 && d->out > 0 && d->buckets > 0, "%s: Mismatched sizes! (non-positive dim)", who);
@@ -737,6 +1043,13 @@ int bt_dense_forward(void *stream, const bt_dense_desc *d, const float *w, const
     BT_REQUIRE(w && bias && x && y, "bt_dense_forward: null pointer");
     BT_REQUIRE(d->buckets == 1 || bucket, "bt_dense_forward: bucketed layer needs bucket indices");
     if (dense_fwd_small_ok(d)) return dense_fwd_small_launch(bt_stream(stream), d, w, bias, x, bucket, y, nullptr, nullptr);
+    if (dense_mid_ok(d)) return dense_mid_launch(bt_stream(stream), d, w, bias, x, bucket, y, false);
+    if (dense_tiny_ok(d)) {
+        BT_LAUNCH(BTK_DENSE_FWD, bt_stream(stream), dense_tiny_fwd_kernel, dim3(bt_div_up((long long)d->batch * d->out, 256)),
+                  dim3(256), 0, w, bias, x, bucket, y, *d);
+        BT_LAUNCH_CHECK();
+        return BT_OK;
+    }
     BT_LAUNCH(BTK_DENSE_FWD, bt_stream(stream), dense_fwd_kernel, dim3(bt_div_up(d->batch, 4)), dim3(256), 0, w, bias, x,
                        bucket, y, *d);
     BT_LAUNCH_CHECK();
@@ -746,8 +1059,10 @@ int bt_dense_forward(void *stream, const bt_dense_desc *d, const float *w, const
 size_t bt_dense_backward_workspace_bytes(const bt_dense_desc *d) {
     if (dense_validate(d, "bt_dense_backward_workspace_bytes")) return 0;
     const int rows = d->out * d->buckets;
-    const int nr = dense_bwd_small_ok(d) ? bt_div_up(d->batch, DBS_RANGE) : bt_div_up(d->batch, DW_RANGE);
-    return bt_align((size_t)nr * rows * d->in * sizeof(float)) + bt_align((size_t)nr * rows * sizeof(float));
+    const bool mid = !dense_bwd_small_ok(d) && (dense_mid_ok(d) || dense_tiny_ok(d));
+    const int nr = dense_bwd_small_ok(d) ? bt_div_up(d->batch, DBS_RANGE) : bt_div_up(d->batch, mid ? DM_RANGE : DW_RANGE);
+    return bt_align((size_t)nr * rows * d->in * sizeof(float)) + bt_align((size_t)nr * rows * sizeof(float)) +
+           (mid ? bt_align((size_t)d->batch * d->out * sizeof(float)) : 0);  // mid path: + gz [B][out]
 }
 
 int bt_dense_backward(void *stream, const bt_dense_desc *d, const float *w, const float *x, const int32_t *bucket,
@@ -767,6 +1082,44 @@ int bt_dense_backward(void *stream, const bt_dense_desc *d, const float *w, cons
     if (small)
         return dense_bwd_small_launch(s, d, w, x, bucket, y, grad_y, dw, dbias, grad_x, nullptr, nullptr, 0, nullptr, part_w,
                                       part_b, nr);
+    if (dense_mid_ok(d) || dense_tiny_ok(d)) {
+        const bool tiny = !dense_mid_ok(d);
+        const int nrm = bt_div_up(d->batch, DM_RANGE);
+        char *ws = static_cast<char *>(workspace);
+        float *pw = reinterpret_cast<float *>(ws);
+        float *pb = reinterpret_cast<float *>(ws + bt_align((size_t)nrm * rows * d->in * sizeof(float)));
+        float *gz = reinterpret_cast<float *>(ws + bt_align((size_t)nrm * rows * d->in * sizeof(float)) +
+                                              bt_align((size_t)nrm * rows * sizeof(float)));
+        const size_t ngz = (size_t)d->batch * d->out;
+        BT_LAUNCH(BTK_DENSE_BWD_DX, s, dense_gz_kernel, dim3(bt_div_up((long long)ngz, 256)), dim3(256), 0, y, grad_y, gz, ngz,
+                  d->act);
+        BT_LAUNCH_CHECK();
+        if (tiny) {
+            if (grad_x) {
+                BT_LAUNCH(BTK_DENSE_BWD_DX, s, dense_tiny_dx_kernel, dim3(bt_div_up((long long)d->batch * d->in, 256)),
+                          dim3(256), 0, w, gz, bucket, grad_x, *d);
+                BT_LAUNCH_CHECK();
+            }
+#define DTW(NB) BT_LAUNCH(BTK_DENSE_BWD_DW, s, dense_tiny_dw_kernel<NB>, dim3(nrm), dim3(d->out * d->in), 0, x, bucket, gz, pw, pb, *d)
+            if (d->buckets <= 1) DTW(1);
+            else if (d->buckets <= 2) DTW(2);
+            else if (d->buckets <= 4) DTW(4);
+            else if (d->buckets <= 8) DTW(8);
+            else DTW(16);
+#undef DTW
+            BT_LAUNCH_CHECK();
+        } else {
+            if (grad_x)
+                if (int rc = dense_mid_launch(s, d, w, nullptr, gz, bucket, grad_x, true)) return rc;
+            BT_LAUNCH(BTK_DENSE_BWD_DW, s, dense_mid_dw_kernel, dim3(nrm, bt_div_up(d->out, DM_OH)), dim3(DM_THREADS), 0, x,
+                      bucket, gz, pw, pb, *d);
+            BT_LAUNCH_CHECK();
+        }
+        BT_LAUNCH(BTK_SUM_PARTIALS, s, sum_partials_t_kernel, dim3(bt_div_up((long long)rows * d->in, 256)), dim3(256), 0, pw,
+                  nrm, rows, d->in, dw);
+        BT_LAUNCH_CHECK();
+        return sum_partials_launch(s, pb, nrm, (size_t)rows, dbias);
+    }
     if (grad_x) {
         BT_LAUNCH(BTK_DENSE_BWD_DX, s, dense_bwd_dx_kernel, dim3(bt_div_up((long long)d->batch * d->in, 256)), dim3(256), 0, w,
                            bucket, y, grad_y, grad_x, *d);

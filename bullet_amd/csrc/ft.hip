@@ -432,7 +432,7 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
                                                           const int32_t *__restrict__ idx1, float *__restrict__ out,
                                                           float *__restrict__ saved, bt_ft_desc d, int ntiles,
                                                           int entries_per_wg, FtHeadSink hs) {
-    extern __shared__ float wl[];  // [(cols + 1)][32]; row `cols` is all zero (target of masked slots)
+    extern __shared__ __align__(16) float wl[];  // [(cols + 1)][32]; row `cols` is all zero (target of masked slots)
     constexpr int SS = fwd_strip_words(NROUND);
     constexpr int TW = PAIR ? 16 : 32;  // output columns per perspective covered by this row tile
     const int rt = blockIdx.x % ntiles, grp = blockIdx.x / ntiles;
@@ -631,7 +631,7 @@ __device__ __forceinline__ void ft_bwd_lds_body(const float *__restrict__ grad_o
                                                 float *__restrict__ partial_w, float *__restrict__ partial_b,
                                                 const bt_ft_desc &d, int ntiles, int chunks_per_input,
                                                 int chunks_per_wg) {
-    extern __shared__ float lds_f[];
+    extern __shared__ __align__(16) float lds_f[];
     float *acc = lds_f;                                   // [cols][32]
     float *gt = acc + (size_t)d.cols * LDS_RT;            // [FT_CHUNK + 1][32], last row = zeros (padding target)
     uint16_t *srt = reinterpret_cast<uint16_t *>(gt + (FT_CHUNK + 1) * LDS_RT);    // [ft_sorted_cap]

@@ -123,7 +123,9 @@ def test_ft_forward_backward_vs_oracle(ft_path, batch, rows, cols, nnz, act, pai
 
 DENSE_CASES = [(777, 2048, 1, 8, "identity"), (300, 1024, 16, 8, "screlu"), (300, 16, 32, 8, "screlu"),
                (300, 32, 1, 8, "identity"), (1000, 64, 1, 1, "identity"), (50, 512, 1, 1, "identity"),
-               (33, 20, 3, 2, "crelu")]
+               (33, 20, 3, 2, "crelu"),
+               # mid-size bucketed path (one bucket's rows in LDS): ragged chunks, single bucket, 2 staging rounds of columns
+               (1111, 256, 5, 3, "crelu"), (130, 2048, 9, 1, "relu"), (64, 512, 32, 8, "screlu")]
 
 
 @pytest.mark.parametrize("batch,in_,out,buckets,act", DENSE_CASES)
