@@ -594,7 +594,7 @@ constexpr int DM_OH = 8;        // output rows per workgroup, dW
 
 bool dense_mid_ok(const bt_dense_desc *d) {
     return d->out > 1 && d->out <= 32 && d->buckets <= 32 && d->in % 256 == 0 && d->in / 256 <= 8 &&
-           (size_t)d->out * (d->in + 4) * sizeof(float) <= 96 * 1024;
+           (size_t)d->out * (d->in + 4) * sizeof(float) <= 144 * 1024;
 }
 
 // positions of the chunk whose bucket is bk, ascending, into s_list; returns their number (all threads)
