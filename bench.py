@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16384, help="positions per GPU per step")
     ap.add_argument("--occupancy", choices=["full", "fixture"], default="full",
                     help="pieces per synthetic position: 32 (worst case) or the batch.bf histogram (mean 16.2)")
+    ap.add_argument("--records", default=None, metavar="FILE.bf",
+                    help="take positions from a bulletformat file (tiled to the batch size) instead of the synthetic "
+                         "generator, e.g. tests/golden/batch.bf: real feature skew (not the contract workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--live-loader", type=int, default=0, metavar="BATCHES",
@@ -147,7 +150,11 @@ def main():
     idesc = lib.make_input_desc("chess768")
     batches, nbar = [], 0.0
     for i in range(n_distinct):
-        rec = synth_records(B, 0xB011E7000 + 2 + 1000 * (rank * n_distinct + i), args.occupancy)
+        if args.records:
+            allrec = np.fromfile(args.records, dtype=np.uint8).reshape(-1, 32)
+            rec = allrec[(np.arange(B) + i * B) % allrec.shape[0]].reshape(-1).copy()
+        else:
+            rec = synth_records(B, 0xB011E7000 + 2 + 1000 * (rank * n_distinct + i), args.occupancy)
         stm, ntm, bk, tg, w = lib.map_batch(idesc, rec, out_buckets=8, blend=0.75, eval_scale=400.0, threads=8)
         cnt = np.where((stm < 0).any(1), (stm < 0).argmax(1), 32)
         nbar += cnt.mean() / n_distinct
@@ -213,7 +220,7 @@ def main():
             "metric": "training positions/sec (whole node) HalfKA-1024 SCReLU net at 1/2/4/8 GPUs",
             "value": value, "unit": "positions/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic" if not args.records else "file:" + os.path.basename(args.records),
             "config": {"workload": "BASELINE configs[1]: Chess768 -> 1024x2 SCReLU -> 1, 8 output buckets, AdamW, "
                                    "fwd+bwd+optimiser step", "batch_per_gpu": B, "global_batch": global_batch,
                        "occupancy": args.occupancy, "mean_active_features": round(float(nbar), 2),
