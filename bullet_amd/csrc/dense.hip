@@ -236,6 +236,9 @@ __global__ __launch_bounds__(1024) void sigmoid_mse_kernel(int batch, const floa
 // ------------------------------------------------------------------ AdamW (multi-tensor, one launch)
 struct AdamTable {
     int n_tensors;
+    int radam;        // 0: AdamW; 1: RAdam (rate scaled by step_size, division by sqrt(v) only when `denom`)
+    float step_size;  // RAdam: rectification factor / bias correction, computed on the host (radam.rs:283-302)
+    int denom;
     int block_start[BT_ADAMW_MAX_TENSORS + 1];  // prefix sum of blocks per tensor
     bt_adamw_tensor t[BT_ADAMW_MAX_TENSORS];
 };
@@ -252,12 +255,42 @@ __device__ __forceinline__ void adam_op(float grad, float rate, float &p, float 
     p = fminf(fmaxf(p, t.min_weight), t.max_weight);
 }
 
+// radam.rs:35-52, in this exact order
+__device__ __forceinline__ void radam_op(float grad, float rate, int denom, float &p, float &m, float &v,
+                                         const bt_adamw_tensor &t) {
+    p *= 1.0f - t.decay * rate;
+    m = t.beta1 * m + (1.0f - t.beta1) * grad;
+    v = t.beta2 * v + (1.0f - t.beta2) * grad * grad;
+    float val = m;
+    if (denom) val /= __fsqrt_rn(v) + 0.00000001f;
+    p -= rate * val;
+    p = fminf(fmaxf(p, t.min_weight), t.max_weight);
+}
+
+// Ranger lookahead: w = s = alpha*w + (1-alpha)*s (ranger.rs:23-44)
+__global__ __launch_bounds__(256) void lookahead_kernel(float *__restrict__ w, float *__restrict__ slow, size_t n,
+                                                        float alpha) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float nw = alpha * w[i] + (1.0f - alpha) * slow[i];
+    w[i] = nw, slow[i] = nw;
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(AdamTable tab, const float *__restrict__ adj_ptr,
                                                     const float *__restrict__ rate_ptr) {
     int ti = 0;
     while (ti + 1 < tab.n_tensors && (int)blockIdx.x >= tab.block_start[ti + 1]) ti++;
     const bt_adamw_tensor &t = tab.t[ti];
-    const float adj = adj_ptr[0], rate = rate_ptr[0];
+    const float adj = adj_ptr[0], rate = tab.radam ? rate_ptr[0] * tab.step_size : rate_ptr[0];
+    if (tab.radam) {
+        const size_t r0 = ((size_t)(blockIdx.x - tab.block_start[ti]) * 256 + threadIdx.x) * 4;
+        for (size_t e = r0; e < t.n && e < r0 + 4; e++) {
+            float p = t.param[e], m = t.momentum[e], v = t.velocity[e];
+            radam_op(adj * t.grad[e], rate, tab.denom, p, m, v, t);
+            t.param[e] = p, t.momentum[e] = m, t.velocity[e] = v;
+        }
+        return;
+    }
     const size_t e0 = ((size_t)(blockIdx.x - tab.block_start[ti]) * 256 + threadIdx.x) * 4;
     if (e0 >= t.n) return;
     if (e0 + 4 <= t.n && (t.n % 4 == 0)) {
@@ -1144,11 +1177,51 @@ int bt_sigmoid_mse(void *stream, int batch, const float *y, const float *targets
     return BT_OK;
 }
 
+static int adam_launch(void *stream, int n_tensors, const bt_adamw_tensor *tensors, const float *adj_dev,
+                       const float *lr_dev, int radam, float step_size, int denom);
+
 int bt_adamw(void *stream, int n_tensors, const bt_adamw_tensor *tensors, const float *adj_dev, const float *lr_dev) {
+    return adam_launch(stream, n_tensors, tensors, adj_dev, lr_dev, 0, 1.0f, 1);
+}
+
+int bt_radam(void *stream, int n_tensors, const bt_adamw_tensor *tensors, const float *adj_dev, const float *lr_dev,
+             int istep, float thr) {
+    BT_REQUIRE(istep >= 1, "bt_radam: step must be >= 1");
+    BT_REQUIRE(n_tensors > 0 && tensors, "bt_radam: null pointer");
+    // RAdam::update, radam.rs:283-302 (f32 arithmetic; betas of the first tensor, as all tensors share RAdamParams)
+    const float beta1 = tensors[0].beta1, beta2 = tensors[0].beta2, step = (float)istep;
+    const float beta2_t = powf(beta2, step);
+    const float n_sma_max = 2.0f / (1.0f - beta2) - 1.0f;
+    const float n_sma = n_sma_max - 2.0f * step * beta2_t / (1.0f - beta2_t);
+    const float dn = 1.0f - powf(beta1, step);
+    float step_size;
+    if (n_sma > thr) {
+        const float p1 = (n_sma - 4.0f) / (n_sma_max - 4.0f), p2 = (n_sma - 2.0f) / n_sma, p3 = n_sma_max / (n_sma_max - 2.0f);
+        step_size = sqrtf((1.0f - beta2_t) * p1 * p2 * p3) / dn;
+    } else {
+        step_size = 1.0f / dn;
+    }
+    return adam_launch(stream, n_tensors, tensors, adj_dev, lr_dev, 1, step_size, n_sma > thr ? 1 : 0);
+}
+
+int bt_lookahead(void *stream, int n_tensors, float *const *params, float *const *slow, const size_t *counts, float alpha) {
+    BT_REQUIRE(n_tensors > 0 && params && slow && counts, "bt_lookahead: null pointer");
+    for (int i = 0; i < n_tensors; i++) {
+        BT_REQUIRE(params[i] && slow[i] && counts[i] > 0, "bt_lookahead: tensor %d has null/empty buffers", i);
+        BT_LAUNCH(BTK_ADAMW, bt_stream(stream), lookahead_kernel, dim3(bt_div_up((long long)counts[i], 256)), dim3(256), 0,
+                  params[i], slow[i], counts[i], alpha);
+        BT_LAUNCH_CHECK();
+    }
+    return BT_OK;
+}
+
+static int adam_launch(void *stream, int n_tensors, const bt_adamw_tensor *tensors, const float *adj_dev,
+                       const float *lr_dev, int radam, float step_size, int denom) {
     BT_REQUIRE(n_tensors > 0 && n_tensors <= BT_ADAMW_MAX_TENSORS, "bt_adamw: n_tensors out of range");
     BT_REQUIRE(tensors && adj_dev && lr_dev, "bt_adamw: null pointer");
     AdamTable tab;
     tab.n_tensors = n_tensors;
+    tab.radam = radam, tab.step_size = step_size, tab.denom = denom;
     int blocks = 0;
     for (int i = 0; i < n_tensors; i++) {
         const bt_adamw_tensor &t = tensors[i];

@@ -21,6 +21,10 @@ struct bt_net {
     float *params = nullptr, *grads = nullptr, *mom = nullptr, *vel = nullptr;
     bool own_params = false, own_grads = false;
     bt_adamw_tensor adam[BT_ADAMW_MAX_TENSORS];
+    // optimiser selection (bt_net_set_optimiser): RAdam / Ranger keep an update counter; Ranger also slow weights
+    int opt_kind = BT_OPT_ADAMW, opt_step = 0, opt_k = 6;
+    float opt_thr = 5.0f, opt_alpha = 0.5f;
+    float *slow = nullptr;
     // activations
     float *hid = nullptr, *saved = nullptr, *g_hid = nullptr, *grad_y = nullptr;
     float *gz0 = nullptr;            // [B] head pre-activation gradient (fused FT backward)
@@ -364,7 +368,7 @@ int bt_net_destroy(bt_net *n) {
     bt_free(n->mom), bt_free(n->vel), bt_free(n->hid), bt_free(n->g_hid), bt_free(n->saved), bt_free(n->grad_y);
     bt_free(n->gz0), bt_free(n->loss_partials), bt_free(n->zpart);
     for (int k = 0; k < BT_MAX_DENSE; k++) bt_free(n->a[k]), bt_free(n->ga[k]), bt_free(n->ap[k]), bt_free(n->gzp[k]);
-    bt_free(n->yfin), bt_free(n->weff);
+    bt_free(n->yfin), bt_free(n->weff), bt_free(n->slow);
     bt_free(n->ft_ws), bt_free(n->dense_ws);
     if (n->ev_fork) (void)hipEventDestroy(n->ev_fork);
     if (n->ev_index) (void)hipEventDestroy(n->ev_index);
@@ -516,6 +520,12 @@ int bt_net_save_checkpoint(bt_net *n, void *stream, const bt_saved_format *fmt, 
         BT_HIP(hipStreamSynchronize(s));
         if (int rc = bt_checkpoint_write(&n->d, host.data(), (opt + parts[i].file).c_str())) return rc;
     }
+    if (n->opt_kind == BT_OPT_RANGER) {  // RangerLookahead::write_to_checkpoint, ranger.rs:124-129
+        std::vector<float> slow(n->n_params);
+        BT_HIP(hipMemcpyAsync(slow.data(), n->slow, n->n_params * sizeof(float), hipMemcpyDeviceToHost, s));
+        BT_HIP(hipStreamSynchronize(s));
+        if (int rc = bt_checkpoint_write(&n->d, slow.data(), (opt + "/slow.bin").c_str())) return rc;
+    }
     if (int rc = bt_save_raw(&n->d, host.data(), fmt, n_fmt, (base + "/raw.bin").c_str())) return rc;
     return bt_save_quantised(&n->d, host.data(), fmt, n_fmt, (base + "/quantised.bin").c_str());
 }
@@ -536,12 +546,41 @@ int bt_net_load_checkpoint(bt_net *n, void *stream, const char *dir) {
         BT_HIP(hipMemcpyAsync(parts[i].dev, host.data(), n->n_params * sizeof(float), hipMemcpyHostToDevice, s));
         BT_HIP(hipStreamSynchronize(s));
     }
+    if (n->opt_kind == BT_OPT_RANGER) {  // ranger.rs:112-122
+        std::fill(host.begin(), host.end(), 0.0f);
+        if (int rc = bt_checkpoint_read(&n->d, host.data(), (opt + "/slow.bin").c_str())) return rc;
+        BT_HIP(hipMemcpyAsync(n->slow, host.data(), n->n_params * sizeof(float), hipMemcpyHostToDevice, s));
+        BT_HIP(hipStreamSynchronize(s));
+    }
     return BT_OK;
 }
 
 int bt_net_optimiser_step(bt_net *n, void *stream, const float *adj_dev, const float *lr_dev) {
     BT_REQUIRE(n, "bt_net_optimiser_step: null net");
-    return bt_adamw(stream, n->n_tensors, n->adam, adj_dev, lr_dev);
+    if (n->opt_kind == BT_OPT_ADAMW) return bt_adamw(stream, n->n_tensors, n->adam, adj_dev, lr_dev);
+    n->opt_step++;  // RAdam::update / RangerLookahead::update count their calls (radam.rs:277, ranger.rs:88)
+    if (int rc = bt_radam(stream, n->n_tensors, n->adam, adj_dev, lr_dev, n->opt_step, n->opt_thr)) return rc;
+    if (n->opt_kind == BT_OPT_RANGER && n->opt_step % n->opt_k == 0) {
+        float *pp[1] = {n->params}, *ss[1] = {n->slow};
+        const size_t cnt[1] = {n->n_params};  // the flat buffers: padding floats are zero on both sides
+        return bt_lookahead(stream, 1, pp, ss, cnt, n->opt_alpha);
+    }
+    return BT_OK;
+}
+
+int bt_net_set_optimiser(bt_net *n, int kind, float n_sma_threshold, float alpha, int k) {
+    BT_REQUIRE(n, "bt_net_set_optimiser: null net");
+    BT_REQUIRE(kind >= BT_OPT_ADAMW && kind <= BT_OPT_RANGER, "bt_net_set_optimiser: unknown optimiser %d", kind);
+    BT_REQUIRE(kind != BT_OPT_RANGER || k >= 1, "bt_net_set_optimiser: k must be >= 1");
+    n->opt_kind = kind, n->opt_step = 0, n->opt_thr = n_sma_threshold, n->opt_alpha = alpha, n->opt_k = k > 0 ? k : 6;
+    BT_HIP(hipMemset(n->mom, 0, n->n_params * sizeof(float)));  // OptimiserState::reset
+    BT_HIP(hipMemset(n->vel, 0, n->n_params * sizeof(float)));
+    if (kind == BT_OPT_RANGER) {
+        if (!n->slow)
+            if (int rc = dmalloc(&n->slow, n->n_params)) return rc;
+        BT_HIP(hipMemset(n->slow, 0, n->n_params * sizeof(float)));  // ranger.rs:71: slow weights start at zero
+    }
+    return BT_OK;
 }
 
 }  // extern "C"

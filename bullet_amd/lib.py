@@ -120,7 +120,7 @@ SYMBOLS = [
     "bt_ft_forward", "bt_ft_backward_workspace_bytes", "bt_ft_backward", "bt_ft_build_index",
     "bt_ft_backward_prebuilt",
     "bt_dense_forward", "bt_dense_backward_workspace_bytes", "bt_dense_backward",
-    "bt_sigmoid_mse", "bt_adamw",
+    "bt_sigmoid_mse", "bt_adamw", "bt_radam", "bt_lookahead", "bt_net_set_optimiser",
     "bt_net_param_count", "bt_net_num_tensors", "bt_net_tensor_size", "bt_net_tensor_offset", "bt_net_create",
     "bt_net_destroy", "bt_net_params", "bt_net_grads", "bt_net_momentum", "bt_net_velocity", "bt_net_set_adamw",
     "bt_net_forward_backward", "bt_net_optimiser_step", "bt_net_forward",
@@ -171,6 +171,10 @@ def load():
     L.bt_dense_backward.argtypes = [C.c_void_p, C.POINTER(DenseDesc)] + [C.c_void_p] * 9 + [C.c_size_t]
     L.bt_sigmoid_mse.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
     L.bt_adamw.argtypes = [C.c_void_p, C.c_int, C.POINTER(AdamwTensor), C.c_void_p, C.c_void_p]
+    L.bt_radam.argtypes = [C.c_void_p, C.c_int, C.POINTER(AdamwTensor), C.c_void_p, C.c_void_p, C.c_int, C.c_float]
+    L.bt_lookahead.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                               C.c_float]
+    L.bt_net_set_optimiser.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int]
     L.bt_net_param_count.argtypes = [C.POINTER(NetDesc)]
     L.bt_net_num_tensors.argtypes = [C.POINTER(NetDesc)]
     L.bt_net_tensor_size.argtypes = [C.POINTER(NetDesc), C.c_int]

@@ -183,6 +183,13 @@ typedef struct {
 #define BT_ADAMW_MAX_TENSORS 16
 int bt_adamw(void *stream, int n_tensors, const bt_adamw_tensor *tensors /* host */, const float *adj_dev,
              const float *lr_dev);
+/* RAdam::update (crates/trainer/src/optimiser/radam.rs:35-52,264-313): same tensor table (decay, betas, clip; the
+ * reference defaults are decay 0, no clip = +-FLT_MAX). `step` is the 1-based update count; the rectification
+ * (step size, whether to divide by sqrt(v)) is computed on the host in f32 as the reference does. */
+int bt_radam(void *stream, int n_tensors, const bt_adamw_tensor *tensors /* host */, const float *adj_dev,
+             const float *lr_dev, int step, float n_sma_threshold);
+/* the lookahead half of Ranger (optimiser/ranger.rs:23-44): param = slow = alpha*param + (1-alpha)*slow */
+int bt_lookahead(void *stream, int n_tensors, float *const *params, float *const *slow, const size_t *counts, float alpha);
 
 /* ------------------------------------------------------------------------------------------
  * 3. The lowered training step for the ValueTrainerBuilder net family
@@ -244,6 +251,12 @@ typedef struct {
 int bt_net_forward_backward(bt_net *net, void *stream, const bt_batch *batch, float *loss_sum_dev);
 /* AdamW on every tensor with g = adj * grad (adj = 1/global_batch), adam.rs:121-131 */
 int bt_net_optimiser_step(bt_net *net, void *stream, const float *adj_dev, const float *lr_dev);
+/* Which OptimiserState the step uses: AdamW (default, adam.rs), RAdam (radam.rs) or Ranger = RAdam + lookahead
+ * (ranger.rs; defaults beta1 0.99, alpha 0.5, k 6; the slow weights start at ZERO as in the reference, ranger.rs:71).
+ * Resets the step counter and the optimiser state (OptimiserState::reset). Per-tensor decay / betas / clip stay
+ * with bt_net_set_adamw. */
+enum { BT_OPT_ADAMW = 0, BT_OPT_RADAM = 1, BT_OPT_RANGER = 2 };
+int bt_net_set_optimiser(bt_net *net, int kind, float n_sma_threshold, float alpha, int k);
 /* forward only (ModelEvaluator, crates/trainer/src/model/evaluator.rs:50-81): raw outputs F32[batch] */
 int bt_net_forward(bt_net *net, void *stream, const bt_batch *batch, float *out_dev, float *loss_sum_dev);
 

@@ -172,6 +172,47 @@ void orc_adamw(float *p, float *m, float *v, const float *g, size_t n, float adj
     }
 }
 
+void orc_radam_step(int istep, float beta1, float beta2, float thr, float *step_size, int *denom) {
+    const float step = (float)istep;
+    const float beta2_t = powf(beta2, step);
+    const float n_sma_max = 2.0f / (1.0f - beta2) - 1.0f;
+    const float n_sma = n_sma_max - 2.0f * step * beta2_t / (1.0f - beta2_t);
+    const float dn = 1.0f - powf(beta1, step);
+    if (n_sma > thr) {
+        const float p1 = (n_sma - 4.0f) / (n_sma_max - 4.0f);
+        const float p2 = (n_sma - 2.0f) / n_sma;
+        const float p3 = n_sma_max / (n_sma_max - 2.0f);
+        *step_size = sqrtf((1.0f - beta2_t) * p1 * p2 * p3) / dn;
+    } else {
+        *step_size = 1.0f / dn;
+    }
+    *denom = n_sma > thr;
+}
+
+void orc_radam(float *p, float *m, float *v, const float *g, size_t n, float adj, float lr, float step_size, int denom,
+               float decay, float beta1, float beta2, float wmin, float wmax) {
+    const float rate = lr * step_size; /* rate_ptr[0] * step_size_ptr[0] */
+    for (size_t i = 0; i < n; i++) {
+        const float grad = adj * g[i];
+        float pi = p[i];
+        pi *= 1.0f - decay * rate;
+        m[i] = beta1 * m[i] + (1.0f - beta1) * grad;
+        v[i] = beta2 * v[i] + (1.0f - beta2) * grad * grad;
+        float val = m[i];
+        if (denom) val /= sqrtf(v[i]) + 0.00000001f;
+        pi -= rate * val;
+        p[i] = minf_(maxf_(pi, wmin), wmax);
+    }
+}
+
+void orc_lookahead(float *w, float *slow, size_t n, float alpha) {
+    for (size_t i = 0; i < n; i++) {
+        const float nw = alpha * w[i] + (1.0f - alpha) * slow[i];
+        w[i] = nw;
+        slow[i] = nw;
+    }
+}
+
 /* ====================================================================== net */
 
 int orc_net_num_tensors(const orc_net_desc *d) { return 2 + 2 * d->n_dense + (d->ft_factoriser > 0 ? 1 : 0); }

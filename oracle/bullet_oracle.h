@@ -73,6 +73,14 @@ float orc_sigmoid(float x);
 void orc_adamw(float *p, float *m, float *v, const float *g, size_t n, float adj, float lr, float decay, float beta1,
                float beta2, float wmin, float wmax);
 
+/* RAdam (crates/trainer/src/optimiser/radam.rs:35-52 kernel, :283-302 host-side step size): `step` is the 1-based
+ * update count. step_size / denom are computed in f32 exactly as the reference does on the host. */
+void orc_radam_step(int step, float beta1, float beta2, float n_sma_threshold, float *step_size, int *denom);
+void orc_radam(float *p, float *m, float *v, const float *g, size_t n, float adj, float lr, float step_size, int denom,
+               float decay, float beta1, float beta2, float wmin, float wmax);
+/* Ranger = RAdam + lookahead every k steps: w = s = alpha*w + (1-alpha)*s (optimiser/ranger.rs:23-44,78-96) */
+void orc_lookahead(float *w, float *slow, size_t n, float alpha);
+
 /* ------------------------------------------------------------------ net */
 
 #define ORC_MAX_DENSE 4

@@ -110,6 +110,21 @@ def net_fwd_bwd(d, params, stm, nstm, buckets, targets, weights=None):
     return float(loss), grads, out
 
 
+def radam_step(step, b1=0.9, b2=0.999, thr=5.0):
+    ss, dn = C.c_float(), C.c_int()
+    lib().orc_radam_step(step, C.c_float(b1), C.c_float(b2), C.c_float(thr), C.byref(ss), C.byref(dn))
+    return ss.value, dn.value
+
+
+def radam(p, m, v, g, adj, lr, step_size, denom, decay=0.0, b1=0.9, b2=0.999, wmin=-3.4028235e38, wmax=3.4028235e38):
+    lib().orc_radam(fp(p), fp(m), fp(v), fp(g), C.c_size_t(p.size), C.c_float(adj), C.c_float(lr), C.c_float(step_size),
+                    C.c_int(denom), C.c_float(decay), C.c_float(b1), C.c_float(b2), C.c_float(wmin), C.c_float(wmax))
+
+
+def lookahead(w, slow, alpha):
+    lib().orc_lookahead(fp(w), fp(slow), C.c_size_t(w.size), C.c_float(alpha))
+
+
 def adamw(p, m, v, g, adj, lr, decay=0.01, b1=0.9, b2=0.999, wmin=-1.98, wmax=1.98):
     lib().orc_adamw(fp(p), fp(m), fp(v), fp(g), C.c_size_t(p.size), C.c_float(adj), C.c_float(lr), C.c_float(decay),
                     C.c_float(b1), C.c_float(b2), C.c_float(wmin), C.c_float(wmax))

@@ -295,3 +295,41 @@ def test_checkpoint_save_load_round_trip_on_device(tmp_path):
         assert np.array_equal(x, y)
     assert step(a, 2) == step(b, 2)
     a.close(), b.close()
+
+
+@pytest.mark.parametrize("kind", ["radam", "ranger"])
+def test_radam_and_ranger_steps_vs_oracle(kind):
+    """optimiser/radam.rs and ranger.rs (RangerParams defaults: decay 0.01, beta1 0.99, clip +-1.98, alpha 0.5, k 6):
+    8 steps, so the rectified branch (n_sma > 5 from step 6 on) and one lookahead are both crossed."""
+    cfg = NETS["cfg1_simple"][0]
+    batches = fixture_batches("chess768", None, False, 1, 0.5, 2, batch=1200)
+    dn, do = lib.make_net_desc(**cfg), ob.make_net(**cfg)
+    params = ob.net_init(do)
+    net = lib.Net(dn, 1200)
+    net.set_params(params)
+    ranger = kind == "ranger"
+    hp = dict(decay=0.01, b1=0.99, b2=0.999, wmin=-1.98, wmax=1.98) if ranger else dict()
+    for t in range(len(params)):
+        if ranger:
+            lib.check(net.L.bt_net_set_adamw(net.h, t, 0.01, 0.99, 0.999, -1.98, 1.98))
+        else:
+            lib.check(net.L.bt_net_set_adamw(net.h, t, 0.0, 0.9, 0.999, -3.4028235e38, 3.4028235e38))
+    lib.check(net.L.bt_net_set_optimiser(net.h, 2 if ranger else 1, 5.0, 0.5, 6))
+    m = [np.zeros_like(p) for p in params]
+    v = [np.zeros_like(p) for p in params]
+    slow = [np.zeros_like(p) for p in params]
+    adj, lr = torch.tensor([1.0 / 1200], device="cuda"), torch.tensor([1e-3], device="cuda")
+    for s in range(1, 9):
+        stm, ntm, bk, tg, w = batches[s % 2]
+        net.forward_backward(net.make_batch(gu.dev(stm), gu.dev(ntm), gu.dev(bk), gu.dev(tg), gu.dev(w)))
+        net.optimiser_step(adj, lr)
+        _, grads, _ = ob.net_fwd_bwd(do, params, stm, ntm, bk, tg, w)
+        ss, dnm = ob.radam_step(s, hp.get("b1", 0.9), 0.999, 5.0)
+        for p_, m_, v_, g_, s_ in zip(params, m, v, grads, slow):
+            ob.radam(p_, m_, v_, g_, 1.0 / 1200, 1e-3, ss, dnm, **hp)
+            if ranger and s % 6 == 0:
+                ob.lookahead(p_, s_, 0.5)
+    torch.cuda.synchronize()
+    for t, (a, b) in enumerate(zip(net.get_tensors(net.params), params)):
+        gu.assert_close(a, b, rtol=1e-4, atol=2e-5, what=f"{kind}: tensor {t} after 8 steps")
+    net.close()
