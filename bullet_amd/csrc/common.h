@@ -1,6 +1,7 @@
 // Shared helpers for libbullet_amd.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -70,10 +71,18 @@ struct BtProfScope {
         if (on) bt_prof_record(id, s, false);
     }
 };
-#define BT_LAUNCH(id, stream, kernel, grid, block, lds, ...)                        \
-    do {                                                                            \
-        BtProfScope prof_scope_(id, stream);                                        \
-        hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);          \
+// A completion event can ride on a kernel's own dispatch packet (hipExtLaunchKernelGGL stop event) instead of a
+// separate hipEventRecord packet, which costs ~6 us of bubble in front of the next kernel of the stream:
+// bt_attach_stop_event(id, ev) arms it for the calling thread's next launch of kernel `id`.
+void bt_attach_stop_event(int kernel_id, hipEvent_t ev);
+hipEvent_t bt_take_stop_event(int kernel_id);
+#define BT_LAUNCH(id, stream, kernel, grid, block, lds, ...)                                        \
+    do {                                                                                            \
+        BtProfScope prof_scope_(id, stream);                                                        \
+        if (hipEvent_t stop_ev_ = bt_take_stop_event(id))                                           \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, stop_ev_, 0, __VA_ARGS__); \
+        else                                                                                        \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                      \
     } while (0)
 
 // ---- internal cross-file entry points (not in the public header)

@@ -209,6 +209,11 @@ int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bo
         if (int rc = bt_internal_ft_forward_head(s, &f, w0, n->params + n->t_off[1], idx, n->hid,
                                                  n->saved, n->params + n->t_off[2], bk, q.buckets, n->zpart))
             return rc;
+        // Cross-stream packets cost a few us of bubble each on this stream. The index join goes here, between the FT
+        // forward and the finishing kernel (it has long been satisfied), and "forward done" (ev_fwd) rides on the
+        // finishing kernel's own dispatch packet instead of a separate hipEventRecord.
+        BT_HIP(hipStreamWaitEvent(s, n->ev_index, 0));
+        bt_attach_stop_event(BTK_DENSE_FWD_SMALL, n->ev_fwd);
         return bt_internal_head_finish(s, &q, n->zpart, bt_internal_ft_head_parts(&f), n->params + n->t_off[3], bk,
                                        b->targets, n->d.use_entry_weights ? b->entry_weights : nullptr, n->a[0],
                                        n->grad_y, want_gz0 ? n->gz0 : nullptr, n->loss_partials, &n->n_loss_partials);
@@ -443,7 +448,7 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
         return BT_OK;
     };
     if (side_head) {
-        BT_HIP(hipEventRecord(n->ev_fwd, s));
+        if (!head_in_ft) BT_HIP(hipEventRecord(n->ev_fwd, s));  // (head_in_ft: recorded by head_finish itself)
         BT_HIP(hipStreamWaitEvent(n->side, n->ev_fwd, 0));  // side: after the index build (stream order) and the forward
         if (int rc = bt_internal_dense_backward_head(n->side, &q0, n->params + n->t_off[2], n->hid, b->buckets, n->a[0],
                                                      n->grad_y, n->grads + n->t_off[2], n->grads + n->t_off[3], nullptr,
@@ -451,7 +456,7 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
                                                      n->dense_ws, n->dense_ws_bytes, true))
             return rc;
         BT_HIP(hipEventRecord(n->ev_head, n->side));
-        BT_HIP(hipStreamWaitEvent(s, n->ev_index, 0));  // main: join the index build
+        if (!head_in_ft) BT_HIP(hipStreamWaitEvent(s, n->ev_index, 0));  // (head_in_ft: joined inside forward_impl)
         if (int rc = bt_internal_ft_backward_fused(s, &f, n->gz0, n->params + n->t_off[2],
                                                    n->d.dense_bucketed[0] ? b->buckets : nullptr, q0.buckets, n->hid,
                                                    n->saved, n->grads + n->t_off[0], n->grads + n->t_off[1], n->ft_ws,

@@ -55,6 +55,18 @@ void bt_prof_record(int id, hipStream_t s, bool begin) {
     }
 }
 
+namespace {
+thread_local int tl_stop_kernel = -1;
+thread_local hipEvent_t tl_stop_event = nullptr;
+}  // namespace
+void bt_attach_stop_event(int kernel_id, hipEvent_t ev) { tl_stop_kernel = kernel_id, tl_stop_event = ev; }
+hipEvent_t bt_take_stop_event(int kernel_id) {
+    if (kernel_id != tl_stop_kernel || !tl_stop_event) return nullptr;
+    hipEvent_t ev = tl_stop_event;
+    tl_stop_kernel = -1, tl_stop_event = nullptr;
+    return ev;
+}
+
 extern "C" {
 
 int bt_profile_start(int max_launches) {
