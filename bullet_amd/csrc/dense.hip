@@ -233,6 +233,64 @@ __global__ __launch_bounds__(1024) void sigmoid_mse_kernel(int batch, const floa
     if (threadIdx.x == 0) loss_sum[0] = red[0];
 }
 
+// the other loss_fn closures (bt_loss): same single-workgroup deterministic reduction
+__global__ __launch_bounds__(1024) void loss_general_kernel(int kind, int batch, int width, const float *__restrict__ y,
+                                                            const float *__restrict__ targets,
+                                                            const float *__restrict__ ew, float power,
+                                                            float *__restrict__ loss_sum, float *__restrict__ grad_y) {
+    __shared__ float red[1024];
+    float part = 0.0f;
+    for (int b = threadIdx.x; b < batch; b += blockDim.x) {
+        const float g = ew ? ew[b] : 1.0f;  // gradient arriving at the per-position loss (reduce_sum_batch, then `ew *`)
+        if (kind == BT_LOSS_SIGMOID_POWER) {
+            const float s = 1.0f / (1.0f + expf(-1.0f * y[b]));
+            const float diff = s + (-1.0f * targets[b]);
+            const float a = fabsf(diff);
+            float l = powf(a, power);  // AbsPower, pointwise.rs:265-268
+            if (ew) l = g * l;
+            part += l;
+            // Power::backward (binary.rs:167-172): grad * (p * a^(p + -1)); Abs' = sgn (0 at 0, write.rs:172-174)
+            const float sg = diff == 0.0f ? 0.0f : (diff > 0.0f ? 1.0f : -1.0f);
+            const float da = g * (power * powf(a, power + -1.0f));
+            grad_y[b] = (da * sg) * (s * (1.0f + (-1.0f * s)));
+        } else {  // BT_LOSS_SOFTMAX_CE: tensor/builder.rs:159-170, autograd/softmax.rs:27-37
+            const float *yb = y + (size_t)b * width, *tb = targets + (size_t)b * width;
+            float mx = yb[0];
+            for (int k = 1; k < width; k++) mx = fmaxf(mx, yb[k]);
+            float den = 0.0f;
+            for (int k = 0; k < width; k++) den += expf(yb[k] + (-1.0f * mx));
+            const float inv = 1.0f / den;
+            float l = 0.0f;
+            for (int k = 0; k < width; k++) {
+                const float p = expf(yb[k] + (-1.0f * mx)) * inv;
+                float lk = -1.0f * (tb[k] * logf(p));
+                if (ew) lk = g * lk;
+                l += lk;
+                grad_y[(size_t)b * width + k] = (p + (-1.0f * tb[k])) * g;
+            }
+            part += l;
+        }
+    }
+    red[threadIdx.x] = part;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_sum[0] = red[0];
+}
+
+__global__ __launch_bounds__(256) void weight_clip_kernel(float *__restrict__ w, size_t n, float lo, float hi) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) w[i] = fmaxf(fminf(w[i], hi), lo);  // clip.rs:25-28: min with max first, then max with min
+}
+
+__global__ __launch_bounds__(256) void weight_decay_kernel(float *__restrict__ w, size_t n, float decay,
+                                                           const float *__restrict__ lr) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) w[i] = w[i] * (1.0f + (-1.0f * (lr[0] * decay)));  // decay.rs:32-35
+}
+
 // ------------------------------------------------------------------ AdamW (multi-tensor, one launch)
 struct AdamTable {
     int n_tensors;
@@ -865,7 +923,7 @@ __global__ __launch_bounds__(1024) void dense_tiny_dw_kernel(const float *__rest
     const int rows = d.out * d.buckets;
     const int b0 = blockIdx.x * DM_RANGE, npos = min(DM_RANGE, d.batch - b0);
     const int o = threadIdx.x / d.in, i = threadIdx.x - o * d.in;  // blockDim.x == out * in
-    if ((int)threadIdx.x < npos) s_bk[threadIdx.x] = (d.buckets > 1) ? bucket[b0 + threadIdx.x] : 0;
+    for (int p = threadIdx.x; p < npos; p += blockDim.x) s_bk[p] = (d.buckets > 1) ? bucket[b0 + p] : 0;  // blockDim may be < DM_RANGE
     __syncthreads();
     float acc[NB], ab[NB];
 #pragma unroll
@@ -1173,6 +1231,38 @@ int bt_sigmoid_mse(void *stream, int batch, const float *y, const float *targets
     BT_REQUIRE(y && targets && loss_sum && grad_y, "bt_sigmoid_mse: null pointer");
     BT_LAUNCH(BTK_SIGMOID_MSE, bt_stream(stream), sigmoid_mse_kernel, dim3(1), dim3(1024), 0, batch, y, targets,
                        entry_weights, loss_sum, grad_y);
+    BT_LAUNCH_CHECK();
+    return BT_OK;
+}
+
+int bt_loss(void *stream, int kind, int batch, int width, const float *y, const float *targets,
+            const float *entry_weights, float power, float *loss_sum, float *grad_y) {
+    if (kind == BT_LOSS_SIGMOID_MSE) {
+        BT_REQUIRE(width == 1, "bt_loss: sigmoid losses take one output per position");
+        return bt_sigmoid_mse(stream, batch, y, targets, entry_weights, loss_sum, grad_y);
+    }
+    BT_REQUIRE(kind == BT_LOSS_SIGMOID_POWER || kind == BT_LOSS_SOFTMAX_CE, "bt_loss: unknown loss kind %d", kind);
+    BT_REQUIRE(batch > 0 && width > 0, "bt_loss: Mismatched sizes! (batch or width <= 0)");
+    BT_REQUIRE(kind != BT_LOSS_SIGMOID_POWER || width == 1, "bt_loss: sigmoid losses take one output per position");
+    BT_REQUIRE(y && targets && loss_sum && grad_y, "bt_loss: null pointer");
+    BT_LAUNCH(BTK_SIGMOID_MSE, bt_stream(stream), loss_general_kernel, dim3(1), dim3(1024), 0, kind, batch, width, y,
+              targets, entry_weights, power, loss_sum, grad_y);
+    BT_LAUNCH_CHECK();
+    return BT_OK;
+}
+
+int bt_weight_clip(void *stream, float *w, size_t n, float min_w, float max_w) {
+    BT_REQUIRE(w && n > 0, "bt_weight_clip: null/empty buffer");
+    BT_LAUNCH(BTK_ADAMW, bt_stream(stream), weight_clip_kernel, dim3(bt_div_up((long long)n, 256)), dim3(256), 0, w, n,
+              min_w, max_w);
+    BT_LAUNCH_CHECK();
+    return BT_OK;
+}
+
+int bt_weight_decay(void *stream, float *w, size_t n, float decay, const float *lr_dev) {
+    BT_REQUIRE(w && n > 0 && lr_dev, "bt_weight_decay: null/empty buffer");
+    BT_LAUNCH(BTK_ADAMW, bt_stream(stream), weight_decay_kernel, dim3(bt_div_up((long long)n, 256)), dim3(256), 0, w, n,
+              decay, lr_dev);
     BT_LAUNCH_CHECK();
     return BT_OK;
 }

@@ -53,7 +53,11 @@ int net_validate(const bt_net_desc *d) {
     BT_REQUIRE(d->n_dense >= 1 && d->n_dense <= BT_MAX_DENSE, "bt_net: n_dense out of range");
     BT_REQUIRE(d->num_buckets >= 1, "bt_net: num_buckets must be >= 1");
     BT_REQUIRE(!d->pairwise || d->ft_out % 2 == 0, "bt_net: pairwise needs even ft_out");
-    BT_REQUIRE(d->dense_out[d->n_dense - 1] == 1, "bt_net: last layer must have one output per bucket");
+    BT_REQUIRE(d->loss_kind >= BT_LOSS_SIGMOID_MSE && d->loss_kind <= BT_LOSS_SOFTMAX_CE, "bt_net: unknown loss kind");
+    if (d->loss_kind == BT_LOSS_SOFTMAX_CE)
+        BT_REQUIRE(d->dense_out[d->n_dense - 1] >= 2, "bt_net: softmax cross-entropy needs >= 2 outputs per bucket");
+    else
+        BT_REQUIRE(d->dense_out[d->n_dense - 1] == 1, "bt_net: last layer must have one output per bucket");
     BT_REQUIRE(2 + 2 * d->n_dense + (d->ft_factoriser > 0) <= BT_ADAMW_MAX_TENSORS, "bt_net: too many tensors");
     BT_REQUIRE(d->ft_factoriser >= 0 && (d->ft_factoriser == 0 || d->num_inputs % d->ft_factoriser == 0),
                "bt_net: ft_factoriser must divide num_inputs");
@@ -327,7 +331,7 @@ int bt_net_create(const bt_net_desc *desc, int max_batch, float *ext_params, flo
     if ((rc = dmalloc(&n->hid, B * K0))) return fail(rc);
     if ((rc = dmalloc(&n->g_hid, B * K0))) return fail(rc);
     if (desc->pairwise && (rc = dmalloc(&n->saved, B * desc->perspectives * desc->ft_out))) return fail(rc);
-    if ((rc = dmalloc(&n->grad_y, B))) return fail(rc);
+    if ((rc = dmalloc(&n->grad_y, B * desc->dense_out[desc->n_dense - 1]))) return fail(rc);
     if ((rc = dmalloc(&n->gz0, B))) return fail(rc);
     if ((rc = dmalloc(&n->loss_partials, 1024))) return fail(rc);
     {
@@ -402,10 +406,11 @@ int bt_net_forward(bt_net *n, void *stream, const bt_batch *b, float *out_dev, f
     hipStream_t s = bt_stream(stream);
     if (int rc = forward_impl(n, s, b, false)) return rc;
     const float *y = net_output(n);
-    if (out_dev) BT_HIP(hipMemcpyAsync(out_dev, y, sizeof(float) * b->batch, hipMemcpyDeviceToDevice, s));
+    const int n_out = n->d.dense_out[n->d.n_dense - 1];
+    if (out_dev) BT_HIP(hipMemcpyAsync(out_dev, y, sizeof(float) * b->batch * n_out, hipMemcpyDeviceToDevice, s));
     if (loss_sum_dev)
-        return bt_sigmoid_mse(s, b->batch, y, b->targets, n->d.use_entry_weights ? b->entry_weights : nullptr,
-                              loss_sum_dev, n->grad_y);
+        return bt_loss(s, n->d.loss_kind, b->batch, n_out, y, b->targets,
+                       n->d.use_entry_weights ? b->entry_weights : nullptr, n->d.loss_power, loss_sum_dev, n->grad_y);
     return BT_OK;
 }
 
@@ -424,8 +429,8 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
     // fusion decisions (shape-dependent, see dense.hip / ft.hip): loss into the final head's forward, the head's dX
     // into the FT backward staging
     bt_dense_desc q_last = dn_desc(n, L - 1, b->batch), q0 = dn_desc(n, 0, b->batch);
-    const bool fuse_loss = bt_internal_dense_forward_loss_ok(&q_last) && bt_internal_dense_head_ok(&q_last) &&
-                           !has_skip(&n->d);  // with skip neurons the loss is taken from yfin, not the last layer
+    const bool fuse_loss = n->d.loss_kind == BT_LOSS_SIGMOID_MSE && bt_internal_dense_forward_loss_ok(&q_last) &&
+                           bt_internal_dense_head_ok(&q_last) && !has_skip(&n->d);  // with skip neurons the loss is taken from yfin, not the last layer
     const bool fuse_ft = bt_internal_dense_head_ok(&q0) && bt_internal_ft_fused_ok(&f, q0.buckets) && !has_post(&n->d, 0);
     // Single-layer head with both fusions: the forward already produced gz (all the FT backward needs), so the
     // head's own backward (dW1, db1, final loss sum) runs on the side stream NEXT TO the FT backward -- one is
@@ -434,8 +439,9 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
     const bool head_in_ft = side_head && bt_internal_ft_forward_head_ok(&f, q0.buckets) && b->batch <= 1024 * 64;
     if (int rc = forward_impl(n, s, b, fuse_loss, side_head, head_in_ft)) return rc;
     if (!fuse_loss)
-        if (int rc = bt_sigmoid_mse(s, b->batch, net_output(n), b->targets,
-                                    n->d.use_entry_weights ? b->entry_weights : nullptr, loss_sum_dev, n->grad_y))
+        if (int rc = bt_loss(s, n->d.loss_kind, b->batch, n->d.dense_out[L - 1], net_output(n), b->targets,
+                             n->d.use_entry_weights ? b->entry_weights : nullptr, n->d.loss_power, loss_sum_dev,
+                             n->grad_y))
             return rc;
     // gradient of the factoriser: sum of the table gradient over the repeats (after the FT backward wrote it)
     auto factor_reduce = [&]() -> int {

@@ -287,6 +287,7 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
                    cfg->end_superbatch >= cfg->start_superbatch,
                "bt_train_run: invalid TrainingSteps");
     const int B = cfg->batch_size, nnz = bt_input_max_active(input);
+    const size_t tw = cfg->wdl_output ? 3 : 1;  // targets per position (value.rs:74)
     const int bps = cfg->batches_per_superbatch;
     const long long total_steps = (long long)(cfg->end_superbatch - cfg->start_superbatch + 1) * bps;
 
@@ -351,7 +352,7 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
         TRY(pinned((void **)&s.stm, sizeof(int32_t) * (size_t)B * nnz));
         TRY(pinned((void **)&s.nstm, sizeof(int32_t) * (size_t)B * nnz));
         TRY(pinned((void **)&s.buckets, sizeof(int32_t) * (size_t)B));
-        TRY(pinned((void **)&s.targets, sizeof(float) * (size_t)B));
+        TRY(pinned((void **)&s.targets, sizeof(float) * (size_t)B * tw));
         TRY(pinned((void **)&s.weights, sizeof(float) * (size_t)B));
         std::memset(s.stm, 0, sizeof(int32_t) * (size_t)B * nnz);
         std::memset(s.nstm, 0, sizeof(int32_t) * (size_t)B * nnz);
@@ -360,7 +361,7 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
         TRY(bt_malloc((void **)&d.stm, sizeof(int32_t) * (size_t)B * nnz));
         TRY(bt_malloc((void **)&d.nstm, sizeof(int32_t) * (size_t)B * nnz));
         TRY(bt_malloc((void **)&d.buckets, sizeof(int32_t) * (size_t)B));
-        TRY(bt_malloc((void **)&d.targets, sizeof(float) * (size_t)B));
+        TRY(bt_malloc((void **)&d.targets, sizeof(float) * (size_t)B * tw));
         TRY(bt_malloc((void **)&d.weights, sizeof(float) * (size_t)B));
     }
     TRY(bt_stream_create(&copy_stream));
@@ -398,7 +399,7 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
             o.blend = bt_wdl_at(&cfg->wdl, batch, sb, cfg->end_superbatch);
             o.eval_scale = cfg->eval_scale;
             o.use_win_rate_model = cfg->use_win_rate_model;
-            o.wdl_output = 0;
+            o.wdl_output = cfg->wdl_output;
             o.threads = cfg->threads;
             HostSlot &s = slots[slot];
             int lrc = bt_reader_next(reader, records.data(), B);
@@ -436,7 +437,7 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
         if (int r2 = bt_memcpy_h2d_async(d.stm, s.stm, sizeof(int32_t) * (size_t)B * nnz, copy_stream)) return r2;
         if (int r2 = bt_memcpy_h2d_async(d.nstm, s.nstm, sizeof(int32_t) * (size_t)B * nnz, copy_stream)) return r2;
         if (int r2 = bt_memcpy_h2d_async(d.buckets, s.buckets, sizeof(int32_t) * (size_t)B, copy_stream)) return r2;
-        if (int r2 = bt_memcpy_h2d_async(d.targets, s.targets, sizeof(float) * (size_t)B, copy_stream)) return r2;
+        if (int r2 = bt_memcpy_h2d_async(d.targets, s.targets, sizeof(float) * (size_t)B * tw, copy_stream)) return r2;
         if (int r2 = bt_memcpy_h2d_async(d.weights, s.weights, sizeof(float) * (size_t)B, copy_stream)) return r2;
         BT_HIP(hipEventRecord(slot_copied[slot], bt_stream(copy_stream)));
         BT_HIP(hipEventRecord(uploaded[set], bt_stream(copy_stream)));

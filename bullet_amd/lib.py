@@ -38,7 +38,11 @@ class NetDesc(C.Structure):
         ("dense_out", C.c_int * MAX_DENSE), ("dense_act", C.c_int * MAX_DENSE),
         ("dense_bucketed", C.c_int * MAX_DENSE), ("use_entry_weights", C.c_int),
         ("ft_factoriser", C.c_int), ("dense_dual", C.c_int * MAX_DENSE), ("dense_skip", C.c_int * MAX_DENSE),
+        ("loss_kind", C.c_int), ("loss_power", C.c_float),
     ]
+
+
+LOSS = {"sigmoid_mse": 0, "sigmoid_power": 1, "softmax_ce": 2}
 
 
 SAVE_TRANSFORM = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_size_t)
@@ -96,7 +100,7 @@ class TrainConfig(C.Structure):
     _fields_ = [("batch_size", C.c_int), ("batches_per_superbatch", C.c_int), ("start_superbatch", C.c_int),
                 ("end_superbatch", C.c_int), ("lr", LrSched), ("wdl", WdlSched), ("eval_scale", C.c_float),
                 ("out_buckets", C.c_int), ("use_win_rate_model", C.c_int), ("threads", C.c_int),
-                ("log_rate", C.c_int)]
+                ("log_rate", C.c_int), ("wdl_output", C.c_int)]
 
 
 BATCH_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_float)
@@ -120,7 +124,8 @@ SYMBOLS = [
     "bt_ft_forward", "bt_ft_backward_workspace_bytes", "bt_ft_backward", "bt_ft_build_index",
     "bt_ft_backward_prebuilt",
     "bt_dense_forward", "bt_dense_backward_workspace_bytes", "bt_dense_backward",
-    "bt_sigmoid_mse", "bt_adamw", "bt_radam", "bt_lookahead", "bt_net_set_optimiser",
+    "bt_sigmoid_mse", "bt_loss", "bt_adamw", "bt_radam", "bt_lookahead", "bt_weight_clip", "bt_weight_decay",
+    "bt_net_set_optimiser",
     "bt_net_param_count", "bt_net_num_tensors", "bt_net_tensor_size", "bt_net_tensor_offset", "bt_net_create",
     "bt_net_destroy", "bt_net_params", "bt_net_grads", "bt_net_momentum", "bt_net_velocity", "bt_net_set_adamw",
     "bt_net_forward_backward", "bt_net_optimiser_step", "bt_net_forward",
@@ -170,6 +175,10 @@ def load():
     L.bt_dense_backward_workspace_bytes.argtypes = [C.POINTER(DenseDesc)]
     L.bt_dense_backward.argtypes = [C.c_void_p, C.POINTER(DenseDesc)] + [C.c_void_p] * 9 + [C.c_size_t]
     L.bt_sigmoid_mse.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+    L.bt_loss.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                          C.c_void_p, C.c_void_p]
+    L.bt_weight_clip.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float]
+    L.bt_weight_decay.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p]
     L.bt_adamw.argtypes = [C.c_void_p, C.c_int, C.POINTER(AdamwTensor), C.c_void_p, C.c_void_p]
     L.bt_radam.argtypes = [C.c_void_p, C.c_int, C.POINTER(AdamwTensor), C.c_void_p, C.c_void_p, C.c_int, C.c_float]
     L.bt_lookahead.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
@@ -239,8 +248,9 @@ def profile_stop():
 
 
 def make_net_desc(num_inputs, nnz, ft_out, ft_act, dense, pairwise=False, perspectives=2, num_buckets=1,
-                  use_entry_weights=False, ft_factoriser=0):
-    """dense: list of (out_per_bucket, act_name, bucketed[, dual[, skip]]); ft_factoriser = NB repeats of l0f"""
+                  use_entry_weights=False, ft_factoriser=0, loss="sigmoid_mse", loss_power=2.0):
+    """dense: list of (out_per_bucket, act_name, bucketed[, dual[, skip]]); ft_factoriser = NB repeats of l0f;
+    loss: "sigmoid_mse" | "sigmoid_power" (with loss_power) | "softmax_ce" (last layer = classes per bucket)"""
     d = NetDesc()
     d.num_inputs, d.nnz, d.ft_out, d.ft_act = num_inputs, nnz, ft_out, ACT[ft_act]
     d.pairwise, d.perspectives, d.num_buckets, d.n_dense = int(pairwise), perspectives, num_buckets, len(dense)
@@ -251,6 +261,7 @@ def make_net_desc(num_inputs, nnz, ft_out, ft_act, dense, pairwise=False, perspe
         d.dense_skip[k] = int(spec[4]) if len(spec) > 4 else 0
     d.use_entry_weights = int(use_entry_weights)
     d.ft_factoriser = ft_factoriser
+    d.loss_kind, d.loss_power = LOSS[loss], float(loss_power)
     return d
 
 
@@ -337,12 +348,12 @@ class Net:
 
     def train(self, input_desc, paths, batch_size, batches_per_superbatch, end_superbatch, lr, wdl, eval_scale=400.0,
               start_superbatch=1, out_buckets=1, threads=4, log_rate=0, win_rate_model=False, on_batch=None,
-              on_superbatch=None):
+              on_superbatch=None, wdl_output=False):
         """run::train through the C ABI. lr / wdl: LrSched / WdlSched. Returns [(superbatch, running_loss, pos/s)]."""
         import torch
         torch.cuda.synchronize()
         cfg = TrainConfig(batch_size, batches_per_superbatch, start_superbatch, end_superbatch, lr, wdl, eval_scale,
-                          out_buckets, int(win_rate_model), threads, log_rate)
+                          out_buckets, int(win_rate_model), threads, log_rate, int(wdl_output))
         report = []
 
         def sb_cb(_u, sb, loss, pps):
@@ -380,7 +391,7 @@ class Net:
 
     def make_batch(self, stm, nstm, buckets, targets, weights=None):
         b = Batch()
-        b.batch = targets.shape[0]
+        b.batch = stm.shape[0] if stm.dim() == 2 else targets.shape[0]
         b.stm = stm.data_ptr()
         b.nstm = nstm.data_ptr() if nstm is not None else None
         b.buckets = buckets.data_ptr() if buckets is not None else None

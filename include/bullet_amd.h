@@ -171,6 +171,20 @@ int bt_dense_backward(void *stream, const bt_dense_desc *desc, const float *w, c
 int bt_sigmoid_mse(void *stream, int batch, const float *y, const float *targets, const float *entry_weights,
                    float *loss_sum, float *grad_y);
 
+/* The other loss functions a ValueTrainerBuilder::loss_fn closure can build, same contract as
+ * bt_sigmoid_mse with `width` outputs / targets per position (y, targets, grad_y: F32[batch*width]):
+ *   BT_LOSS_SIGMOID_MSE    sigmoid(y).squared_error(t)                         (width 1)
+ *   BT_LOSS_SIGMOID_POWER  sigmoid(y).power_error(t, power) = |s - t|^power    (width 1; model/builder.rs:345-358,
+ *                          AbsPower lowering pointwise.rs:248-269, Power::backward binary.rs:167-172, Abs' = sgn with
+ *                          sgn(0) = 0 as the device code writes it, gpu/src/pointwise/write.rs:172-174)
+ *   BT_LOSS_SOFTMAX_CE     y.softmax_crossentropy_loss(t) = -t*log(softmax(y)), summed over the `width` classes
+ *                          (wdl_output: width 3; autograd/softmax.rs:27-37, softmax = tensor/builder.rs:159-170:
+ *                          exp(y - max) * (1 / sum), gradient (softmax - t) * grad)
+ * loss_sum[0] = sum over positions (and classes) of entry_weight * loss. */
+enum { BT_LOSS_SIGMOID_MSE = 0, BT_LOSS_SIGMOID_POWER = 1, BT_LOSS_SOFTMAX_CE = 2 };
+int bt_loss(void *stream, int kind, int batch, int width, const float *y, const float *targets,
+            const float *entry_weights, float power, float *loss_sum, float *grad_y);
+
 /* AdamW, crates/trainer/src/optimiser/adam.rs:29-62,98-235; one launch for all weight tensors
  * (the reference launches once per tensor, optimiser.rs:175-187). adj_dev / lr_dev are 1-element
  * device buffers exactly as in run.rs:130-133. */
@@ -190,6 +204,11 @@ int bt_radam(void *stream, int n_tensors, const bt_adamw_tensor *tensors /* host
              const float *lr_dev, int step, float n_sma_threshold);
 /* the lookahead half of Ranger (optimiser/ranger.rs:23-44): param = slow = alpha*param + (1-alpha)*slow */
 int bt_lookahead(void *stream, int n_tensors, float *const *params, float *const *slow, const size_t *counts, float alpha);
+/* the kernels of the WeightClipping / WeightDecay optimiser wrappers (optimiser/clip.rs:18-31, decay.rs:18-40), for
+ * callers that compose them around an update themselves (Placement::Before / After = call order):
+ * clip: w = max(min(w, max), min); decay: w = w * (1 + -1 * (lr * decay)), lr read from its 1-element device buffer */
+int bt_weight_clip(void *stream, float *w, size_t n, float min_w, float max_w);
+int bt_weight_decay(void *stream, float *w, size_t n, float decay, const float *lr_dev);
 
 /* ------------------------------------------------------------------------------------------
  * 3. The lowered training step for the ValueTrainerBuilder net family
@@ -217,6 +236,10 @@ typedef struct {
     int dense_skip[BT_MAX_DENSE]; /* s: the last s outputs of layer k are sliced off and added to the net output
                                      (slice_rows + `out + skip_neuron`, test2.rs:54-64); next layer sees
                                      (dense_out - s) * (dual ? 2 : 1) inputs */
+    int loss_kind;                /* BT_LOSS_* (0 = sigmoid MSE). BT_LOSS_SOFTMAX_CE: the last layer has dense_out = number
+                                     of classes (3 for wdl_output, value/builder.rs:133) and targets are
+                                     F32[batch * classes] */
+    float loss_power;             /* BT_LOSS_SIGMOID_POWER exponent */
 } bt_net_desc;
 
 typedef struct bt_net bt_net; /* opaque: weights, AdamW state, gradients, activations, scratch */
@@ -349,6 +372,8 @@ typedef struct {
     int use_win_rate_model;
     int threads;             /* LocalSettings::threads */
     int log_rate;            /* progress line every log_rate batches (reference: 128); 0 = silent */
+    int wdl_output;          /* ValueTrainerBuilder::wdl_output: 3-way one-hot targets (value.rs:96-101) for a net
+                                with loss_kind = BT_LOSS_SOFTMAX_CE and 3 outputs */
 } bt_train_config;
 typedef void (*bt_batch_callback)(void *user, int superbatch, int batch, float loss);
 typedef void (*bt_superbatch_callback)(void *user, int superbatch, float running_loss, float positions_per_sec);

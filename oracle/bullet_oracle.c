@@ -205,6 +205,59 @@ void orc_radam(float *p, float *m, float *v, const float *g, size_t n, float adj
     }
 }
 
+float orc_loss(int kind, int batch, int width, const float *y, const float *targets, const float *ew, float power,
+               float *grad_y) {
+    float loss = 0.0f;
+    for (int b = 0; b < batch; b++) {
+        const float g = ew ? ew[b] : 1.0f;
+        if (kind == ORC_LOSS_SOFTMAX_CE) {
+            const float *yb = y + (size_t)b * width, *tb = targets + (size_t)b * width;
+            float mx = yb[0];
+            for (int k = 1; k < width; k++) mx = yb[k] > mx ? yb[k] : mx; /* reduce_max */
+            float den = 0.0f;
+            for (int k = 0; k < width; k++) den = den + expf(yb[k] + (-1.0f * mx)); /* reduce_sum of exp(x - max) */
+            const float inv = 1.0f / den;                                           /* exps / denom = exps * (1/denom) */
+            float l = 0.0f;
+            for (int k = 0; k < width; k++) {
+                const float p = expf(yb[k] + (-1.0f * mx)) * inv;
+                float lk = -1.0f * (tb[k] * logf(p));
+                if (ew) lk = g * lk;
+                l = l + lk;
+                if (grad_y) grad_y[(size_t)b * width + k] = (p + (-1.0f * tb[k])) * g;
+            }
+            loss = loss + l;
+            continue;
+        }
+        const float s = orc_sigmoid(y[b]);
+        const float diff = s + (-1.0f * targets[b]);
+        float l, dd;
+        if (kind == ORC_LOSS_SIGMOID_POWER) {
+            const float a = fabsf(diff);
+            l = powf(a, power);
+            const float sg = diff == 0.0f ? 0.0f : (diff > 0.0f ? 1.0f : -1.0f);
+            dd = (g * (power * powf(a, power + -1.0f))) * sg;
+        } else {
+            l = diff * diff;
+            dd = g * diff + g * diff;
+        }
+        if (ew) l = g * l;
+        loss = loss + l;
+        if (grad_y) grad_y[b] = dd * (s * (1.0f + (-1.0f * s)));
+    }
+    return loss;
+}
+
+void orc_weight_clip(float *w, size_t n, float min_w, float max_w) {
+    for (size_t i = 0; i < n; i++) {
+        float high = w[i] < max_w ? w[i] : max_w;
+        w[i] = high > min_w ? high : min_w;
+    }
+}
+
+void orc_weight_decay(float *w, size_t n, float decay, float lr) {
+    for (size_t i = 0; i < n; i++) w[i] = w[i] * (1.0f + (-1.0f * (lr * decay)));
+}
+
 void orc_lookahead(float *w, float *slow, size_t n, float alpha) {
     for (size_t i = 0; i < n; i++) {
         const float nw = alpha * w[i] + (1.0f - alpha) * slow[i];
@@ -357,6 +410,11 @@ static float net_forward_impl(const orc_net_desc *d, int B, const float *const *
 
     /* a11: loss = sum_b w_b (sigmoid(y_b) - t_b)^2, value/builder.rs:137-142 */
     const float *y = A->y;
+    if (d->loss_kind != ORC_LOSS_SIGMOID_MSE) {
+        if (net_out) memcpy(net_out, y, sizeof(float) * (size_t)B * out_last);
+        return orc_loss(d->loss_kind, B, out_last, y, targets, d->use_entry_weights ? entry_weights : NULL,
+                        d->loss_power, NULL);
+    }
     A->sig = (float *)malloc(sizeof(float) * (size_t)B);
     float loss = 0.0f;
     for (int b = 0; b < B; b++) {
@@ -406,7 +464,10 @@ float orc_net_forward_backward(const orc_net_desc *d, int B, const float *const 
     int out_last = dense_width(d, d->n_dense - 1);
     float *gz = (float *)malloc(sizeof(float) * (size_t)B * out_last); /* grad wrt activated output of last layer */
     float *gy = (float *)malloc(sizeof(float) * (size_t)B * out_last); /* grad wrt the net output (skip neurons get it too) */
-    for (int b = 0; b < B; b++) {
+    if (d->loss_kind != ORC_LOSS_SIGMOID_MSE)
+        (void)orc_loss(d->loss_kind, B, out_last, A.y, targets, d->use_entry_weights ? entry_weights : NULL,
+                       d->loss_power, gz);
+    for (int b = 0; b < B && d->loss_kind == ORC_LOSS_SIGMOID_MSE; b++) {
         float s = A.sig[b];
         float g = d->use_entry_weights ? entry_weights[b] : 1.0f;
         float diff = s + (-1.0f * targets[b]);

@@ -81,6 +81,20 @@ void orc_radam(float *p, float *m, float *v, const float *g, size_t n, float adj
 /* Ranger = RAdam + lookahead every k steps: w = s = alpha*w + (1-alpha)*s (optimiser/ranger.rs:23-44,78-96) */
 void orc_lookahead(float *w, float *slow, size_t n, float alpha);
 
+/* Loss functions a ValueTrainerBuilder::loss_fn closure builds. Returns sum_b ew_b * loss_b (ew may be NULL) and
+ * writes grad_y [batch*width] = d(sum)/dy (may be NULL).
+ *   SIGMOID_MSE   (sigmoid(y) - t)^2                    model/builder.rs:351-354
+ *   SIGMOID_POWER |sigmoid(y) - t|^power                model/builder.rs:345-358, AbsPower pointwise.rs:248-269,
+ *                 Power::backward binary.rs:167-172, Abs' = sgn (unary.rs:146; 0 at 0 as gpu write.rs:172-174)
+ *   SOFTMAX_CE    -sum_k t_k log(softmax(y)_k)          autograd/softmax.rs:27-37, softmax tensor/builder.rs:159-170 */
+enum { ORC_LOSS_SIGMOID_MSE = 0, ORC_LOSS_SIGMOID_POWER = 1, ORC_LOSS_SOFTMAX_CE = 2 };
+float orc_loss(int kind, int batch, int width, const float *y, const float *targets, const float *entry_weights,
+               float power, float *grad_y);
+
+/* WeightClipping / WeightDecay kernels, optimiser/clip.rs:18-31, decay.rs:18-40 */
+void orc_weight_clip(float *w, size_t n, float min_w, float max_w);
+void orc_weight_decay(float *w, size_t n, float decay, float lr);
+
 /* ------------------------------------------------------------------ net */
 
 #define ORC_MAX_DENSE 4
@@ -109,6 +123,8 @@ typedef struct {
     int dense_dual[ORC_MAX_DENSE];     /* 1: x -> concat(x, x*x) before the activation (test2.rs:58-59)        */
     int dense_skip[ORC_MAX_DENSE];     /* s: the last s outputs of layer k bypass the rest of the net and are added
                                           to the final output (slice_rows + `out + skip_neuron`, test2.rs:54-64) */
+    int loss_kind;                     /* ORC_LOSS_*; softmax CE: dense_out[last] classes, targets [batch][classes] */
+    float loss_power;                  /* exponent of ORC_LOSS_SIGMOID_POWER */
 } orc_net_desc;
 
 /* number of weight tensors: l0w,l0b,l1w,l1b,... and, last, l0f when ft_factoriser > 0 */

@@ -20,7 +20,11 @@ class NetDesc(C.Structure):
         ("dense_out", C.c_int * MAX_DENSE), ("dense_act", C.c_int * MAX_DENSE),
         ("dense_bucketed", C.c_int * MAX_DENSE), ("use_entry_weights", C.c_int),
         ("ft_factoriser", C.c_int), ("dense_dual", C.c_int * MAX_DENSE), ("dense_skip", C.c_int * MAX_DENSE),
+        ("loss_kind", C.c_int), ("loss_power", C.c_float),
     ]
+
+
+LOSS = {"sigmoid_mse": 0, "sigmoid_power": 1, "softmax_ce": 2}
 
 
 class InputDesc(C.Structure):
@@ -50,6 +54,7 @@ def lib():
         _lib.orc_net_forward.restype = C.c_float
         _lib.orc_sigmoid.restype = C.c_float
         _lib.orc_sigmoid.argtypes = [C.c_float]
+        _lib.orc_loss.restype = C.c_float
         _lib.orc_net_tensor_size.restype = C.c_size_t
         _lib.orc_rng_next_u64.restype = C.c_uint64
         _lib.orc_rng_standard_normal.restype = C.c_double
@@ -70,7 +75,7 @@ def vp(a):
 
 
 def make_net(num_inputs, nnz, ft_out, ft_act, dense, pairwise=False, perspectives=2, num_buckets=1,
-             use_entry_weights=False, ft_factoriser=0):
+             use_entry_weights=False, ft_factoriser=0, loss="sigmoid_mse", loss_power=2.0):
     """dense: list of (out_per_bucket, act_name, bucketed[, dual[, skip]])"""
     d = NetDesc()
     d.num_inputs, d.nnz, d.ft_out, d.ft_act = num_inputs, nnz, ft_out, ACT[ft_act]
@@ -82,6 +87,7 @@ def make_net(num_inputs, nnz, ft_out, ft_act, dense, pairwise=False, perspective
         d.dense_skip[k] = int(spec[4]) if len(spec) > 4 else 0
     d.use_entry_weights = int(use_entry_weights)
     d.ft_factoriser = ft_factoriser
+    d.loss_kind, d.loss_power = LOSS[loss], float(loss_power)
     return d
 
 
@@ -100,10 +106,29 @@ def net_init(d, seed=198273612, ft_eff=0):
     return params
 
 
+def loss(kind, y, targets, weights=None, power=2.0):
+    """-> (loss sum, grad_y); y, targets: [batch] or [batch, width]"""
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    B = y.shape[0]
+    width = y.size // B
+    gy = np.zeros_like(y)
+    w = fp(weights) if weights is not None else None
+    l = lib().orc_loss(LOSS[kind], B, width, fp(y), fp(targets), w, C.c_float(power), fp(gy))
+    return float(l), gy
+
+
+def weight_clip(w, lo, hi):
+    lib().orc_weight_clip(fp(w), C.c_size_t(w.size), C.c_float(lo), C.c_float(hi))
+
+
+def weight_decay(w, decay, lr):
+    lib().orc_weight_decay(fp(w), C.c_size_t(w.size), C.c_float(decay), C.c_float(lr))
+
+
 def net_fwd_bwd(d, params, stm, nstm, buckets, targets, weights=None):
-    B = targets.shape[0]
+    B = stm.shape[0]
     grads = [np.zeros_like(p) for p in params]
-    out = np.zeros(B, dtype=np.float32)
+    out = np.zeros(B * d.dense_out[d.n_dense - 1], dtype=np.float32)
     w = weights if weights is not None else np.ones(B, dtype=np.float32)
     loss = lib().orc_net_forward_backward(C.byref(d), B, ptr_array(params), ptr_array(grads), ip(stm), ip(nstm),
                                           ip(buckets), fp(targets), fp(w), fp(out))

@@ -25,7 +25,7 @@ def run_steps(cfg, batches, steps, lr=0.001, ft_eff=0, seed=198273612, clip=None
     batches: list of (stm, ntm, buckets, targets, weights). Returns per-step losses and final tensors."""
     dn, do = lib.make_net_desc(**cfg), ob.make_net(**cfg)
     params = ob.net_init(do, seed, ft_eff)
-    B = batches[0][3].shape[0]
+    B = batches[0][0].shape[0]
     net = lib.Net(dn, B)
     net.set_params(params)
     if clip:
@@ -157,6 +157,40 @@ def test_net_step_vs_oracle(name):
         gu.assert_close(a, b, rtol=1e-4, atol=2e-5, what=f"{name}: tensor {t} after 4 steps")
 
 
+@pytest.mark.parametrize("name", ["wdl_softmax_ce", "wdl_bucketed_multilayer", "power_loss"])
+def test_other_loss_functions_net_vs_oracle(name):
+    """wdl_output nets (3 outputs, softmax cross-entropy on one-hot W/D/L targets, value.rs:96-101) and the
+    power_error loss, whole steps against the oracle."""
+    wdl = name != "power_loss"
+    rec = np.fromfile(GOLDEN, dtype=np.uint8).reshape(-1, 32)[:1200]
+    idesc = lib.make_input_desc("chess768")
+    nb = 8 if name == "wdl_bucketed_multilayer" else 1
+    stm, ntm, bk, tg, w = lib.map_batch(idesc, rec.reshape(-1).copy(), out_buckets=nb, blend=0.6, wdl=wdl, threads=2)
+    if wdl:
+        assert tg.shape[0] == 3 * 1200 and set(np.unique(tg)) == {0.0, 1.0}
+    cfg = {
+        "wdl_softmax_ce": dict(num_inputs=768, nnz=32, ft_out=64, ft_act="screlu", dense=[(3, "identity", False)],
+                               loss="softmax_ce"),
+        "wdl_bucketed_multilayer": dict(num_inputs=768, nnz=32, ft_out=64, ft_act="crelu", num_buckets=8,
+                                        dense=[(8, "screlu", True), (3, "identity", True)], loss="softmax_ce",
+                                        use_entry_weights=True),
+        "power_loss": dict(num_inputs=768, nnz=32, ft_out=128, ft_act="screlu", dense=[(1, "identity", False)],
+                           loss="sigmoid_power", loss_power=2.5),
+    }[name]
+    if cfg.get("use_entry_weights"):
+        w = (np.random.default_rng(2).random(1200) + 0.5).astype(np.float32)
+    r = run_steps(cfg, [(stm, ntm, bk, tg, w)], 4)
+    dg, og = r["first_grads"]
+    for t, (a, b) in enumerate(zip(dg, og)):
+        scale = max(float(np.abs(b).max()), 1e-6)
+        gu.assert_close(a, b, rtol=2e-4, atol=2e-5 * scale, what=f"{name}: grad tensor {t}")
+    for a, b in zip(r["dev_loss"], r["orc_loss"]):
+        assert abs(a - b) <= 1e-5 * abs(b) + 1e-7, (r["dev_loss"], r["orc_loss"])
+    for t, (a, b) in enumerate(zip(r["dev_params"], r["orc_params"])):
+        gu.assert_close(a, b, rtol=1e-4, atol=2e-5, what=f"{name}: tensor {t} after 4 steps")
+    assert r["dev_loss"][-1] < r["dev_loss"][0]  # it learns
+
+
 def test_ataxx_net_vs_oracle():
     """examples/ataxx.rs shape (F=147, N=49, H=256) on synthetic AtaxxBoard records."""
     rng = np.random.default_rng(11)
@@ -231,6 +265,36 @@ def test_train_run_reproduces_reference_examples(hidden, expected):
                     threads=4, on_batch=lambda sb, b, l: per_batch.append((sb, b, l)))
     assert [r[0] for r in rep] == list(range(1, 11)) and [p[:2] for p in per_batch] == [(i, 0) for i in range(1, 11)]
     assert "%.6f" % rep[-1][1] == expected
+    net.close()
+
+
+def test_train_run_wdl_output_matches_manual_steps():
+    """bt_train_run with wdl_output (one-hot W/D/L targets, 3-output softmax-CE net) == the same batches mapped and
+    stepped by hand through the C ABI."""
+    cfg = dict(num_inputs=768, nnz=32, ft_out=32, ft_act="screlu", dense=[(3, "identity", False)], loss="softmax_ce")
+    idesc, B = lib.make_input_desc("chess768"), 2048
+    net = lib.Net(lib.make_net_desc(**cfg), B)
+    net.init_weights(seed=5)
+    per_batch = []
+    net.train(idesc, [GOLDEN], B, 2, 2, lib.LrSched(lib.LR["constant"], 0.001, 0, 0, 0),
+              lib.WdlSched(lib.WDL["constant"], 0.5, 0, 0), threads=2, wdl_output=True,
+              on_batch=lambda sb, b, l: per_batch.append(l))
+    w_run = net.params.clone()
+    net.close()
+    net = lib.Net(lib.make_net_desc(**cfg), B)
+    net.init_weights(seed=5)
+    rec = np.fromfile(GOLDEN, dtype=np.uint8).reshape(-1, 32)
+    adj, lrd = torch.tensor([1.0 / B], device="cuda"), torch.tensor([0.001], device="cuda")
+    manual = []
+    for i in range(4):
+        sel = np.arange(i * B, (i + 1) * B) % rec.shape[0]
+        stm, ntm, bk, tg, w = lib.map_batch(idesc, rec[sel].reshape(-1).copy(), blend=0.5, wdl=True, threads=2)
+        net.forward_backward(net.make_batch(gu.dev(stm), gu.dev(ntm), gu.dev(bk), gu.dev(tg), gu.dev(w)))
+        net.optimiser_step(adj, lrd)
+        torch.cuda.synchronize()
+        manual.append(net.loss.item() / B)
+    assert per_batch == manual and torch.equal(w_run, net.params)
+    assert 0.9 < manual[0] < 1.3  # ~ln 3 at initialisation
     net.close()
 
 

@@ -123,7 +123,7 @@ def test_ft_forward_backward_vs_oracle(ft_path, batch, rows, cols, nnz, act, pai
 
 DENSE_CASES = [(777, 2048, 1, 8, "identity"), (300, 1024, 16, 8, "screlu"), (300, 16, 32, 8, "screlu"),
                (300, 32, 1, 8, "identity"), (1000, 64, 1, 1, "identity"), (50, 512, 1, 1, "identity"),
-               (33, 20, 3, 2, "crelu"),
+               (33, 20, 3, 2, "crelu"), (300, 8, 3, 8, "identity"),  # fewer threads (out*in) than positions per range
                # mid-size bucketed path (one bucket's rows in LDS): ragged chunks, single bucket, 2 staging rounds of columns
                (1111, 256, 5, 3, "crelu"), (130, 2048, 9, 1, "relu"), (64, 512, 32, 8, "screlu")]
 
@@ -202,6 +202,51 @@ def test_sigmoid_mse_vs_oracle(batch, use_w):
                                tl.data_ptr(), tg.data_ptr()))
     assert abs(tl.item() - l_ref) <= 2e-6 * max(1.0, l_ref) * np.sqrt(batch) ** 0.5
     gu.assert_close(tg.cpu().numpy(), gy_ref, rtol=2e-5, atol=1e-7, what="grad_y")
+
+
+@pytest.mark.parametrize("kind,width,power,use_w", [("sigmoid_power", 1, 2.5, False), ("sigmoid_power", 1, 2.0, True),
+                                                   ("softmax_ce", 3, 0.0, False), ("softmax_ce", 3, 0.0, True),
+                                                   ("softmax_ce", 7, 0.0, False), ("sigmoid_mse", 1, 0.0, True)])
+def test_loss_kinds_vs_oracle(kind, width, power, use_w):
+    """power_error / softmax cross-entropy. expf/logf/powf are the device's libm, so a few ulp per
+    element against glibc: rtol 1e-5 on the gradient, 1e-6 * sqrt(batch) relative on the summed loss."""
+    batch = 3000
+    rng = np.random.default_rng(width * 10 + use_w)
+    y = (rng.standard_normal((batch, width)) * 2).astype(np.float32)
+    if kind == "softmax_ce":
+        t = np.zeros((batch, width), np.float32)
+        t[np.arange(batch), rng.integers(0, width, batch)] = 1.0
+        t[::7] = rng.dirichlet(np.ones(width), size=t[::7].shape[0]).astype(np.float32)  # soft targets too
+    else:
+        t = rng.random((batch, width)).astype(np.float32)
+        t[5] = ob.lib().orc_sigmoid(float(y[5, 0]))  # diff == 0: sgn(0) = 0 branch
+    w = (rng.random(batch) + 0.5).astype(np.float32) if use_w else None
+    l_ref, gy_ref = ob.loss(kind, y, t, w, power)
+    ty, tt = gu.dev(y), gu.dev(t)
+    tw = gu.dev(w) if use_w else None
+    tl, tg = torch.zeros(1, device="cuda"), torch.zeros(batch * width, device="cuda")
+    lib.check(L.bt_loss(gu.stream(), lib.LOSS[kind], batch, width, ty.data_ptr(), tt.data_ptr(),
+                        tw.data_ptr() if use_w else None, power, tl.data_ptr(), tg.data_ptr()))
+    assert abs(tl.item() - l_ref) <= 1e-6 * np.sqrt(batch) * max(1.0, abs(l_ref))
+    gu.assert_close(tg.cpu().numpy().reshape(batch, width), gy_ref, rtol=1e-5, atol=2e-7, what="grad_y")
+    assert L.bt_loss(gu.stream(), 1, batch, 3, ty.data_ptr(), tt.data_ptr(), None, 2.0, tl.data_ptr(), tg.data_ptr()) == 1
+    assert L.bt_loss(gu.stream(), 9, batch, 1, ty.data_ptr(), tt.data_ptr(), None, 2.0, tl.data_ptr(), tg.data_ptr()) == 1
+
+
+def test_weight_clip_and_decay_vs_oracle():
+    """kernels of the WeightClipping / WeightDecay wrappers (clip.rs:18-31, decay.rs:18-40): bit-exact (one rounding
+    each, no contraction possible in the clip; the decay factor is formed the same way)"""
+    rng = np.random.default_rng(11)
+    w = (rng.standard_normal(100003) * 2).astype(np.float32)
+    dw = gu.dev(w)
+    lr = torch.tensor([0.00123], device="cuda")
+    lib.check(L.bt_weight_decay(gu.stream(), dw.data_ptr(), w.size, 0.01, lr.data_ptr()))
+    lib.check(L.bt_weight_clip(gu.stream(), dw.data_ptr(), w.size, -1.98, 1.5))
+    ob.weight_decay(w, 0.01, float(np.float32(0.00123)))
+    ob.weight_clip(w, -1.98, 1.5)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(dw.cpu().numpy(), w)
+    assert w.max() == 1.5 and w.min() == np.float32(-1.98)
 
 
 def test_adamw_multi_tensor_vs_oracle():
