@@ -93,7 +93,15 @@ bool bt_internal_ft_forward_head_ok(const bt_ft_desc *d, int head_rows);
 int bt_internal_ft_head_parts(const bt_ft_desc *d);
 int bt_internal_ft_forward_head(void *stream, const bt_ft_desc *d, const float *w, const float *bias,
                                 const int32_t *const *idx, float *out, float *saved, const float *w1,
-                                const int32_t *bucket, int head_rows, float *zpart);
+                                const int32_t *bucket, int head_rows, float *zpart, void *workspace,
+                                size_t workspace_bytes);
+// the two halves of bt_ft_build_index: segment entry lists (needed by the forward of a segment-grouped table; no-op
+// otherwise) and the per-chunk sorted lists (backward only); bt_internal_ft_grouped: does the plan use the lists?
+int bt_internal_ft_build_groups(void *stream, const bt_ft_desc *d, const int32_t *const *idx, void *workspace,
+                                size_t workspace_bytes);
+int bt_internal_ft_build_sorted(void *stream, const bt_ft_desc *d, const int32_t *const *idx, void *workspace,
+                                size_t workspace_bytes);
+bool bt_internal_ft_grouped(const bt_ft_desc *d);
 // y = f(sum of the partials in order + bias[bucket]); sigmoid-MSE, its gradient, gz and loss partials like
 // bt_internal_dense_forward_loss
 int bt_internal_head_finish(void *stream, const bt_dense_desc *d, const float *zpart, int nparts, const float *bias,

@@ -16,6 +16,7 @@
 // sorted by feature (stable, so ascending entry order inside a feature) plus per-feature offsets.
 // Every dW element is then summed chunk by chunk, entry by entry, in that fixed order: the result is
 // bit-identical run to run (the reference's atomicAdd order is arbitrary).
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -127,6 +128,130 @@ __global__ __launch_bounds__(256) void ft_fwd_generic(const float *__restrict__ 
     vstore<VEC>(out + (size_t)b * d.out_ld + (size_t)k * out_w + r0, o);
 }
 
+// ------------------------------------------------------------------ segment groups (bt_ft_desc.segment)
+// King-bucketed input sets draw all features of an entry e = (input, position) from one segment of `segment`
+// columns. Entries are counting-sorted by segment (stable: ascending entry id inside a segment) into `elist`;
+// the LDS-resident kernels then run per (row tile, segment) on slices of that list:
+//   chunks : <= FT_CHUNK consecutive elist entries of one segment  (unit of the sorted index / backward staging)
+//   fitems : <= fwd_item consecutive elist entries of one segment   (one forward workgroup per row tile)
+//   bitems : <= g_ch consecutive chunks of one segment              (one backward workgroup per row tile)
+// All tables live in the workspace and are built on the device (no host sync); grids are sized for the worst
+// case and workgroups beyond the counts exit at once.
+struct FtGrp {
+    const int *elist;     // [E]
+    const int4 *items;    // forward: fitems {seg, start, count}; backward: bitems {seg, first chunk, n chunks}
+    const int4 *chunks;   // {seg, start, count}
+    const int *counts;    // [0] n fitems, [1] n bitems, [2] n chunks
+    int *viol;            // indices found outside their entry's segment
+    int tile_cols;        // = segment
+};
+
+constexpr int GRP_BLOCK = 256;
+
+// pass 1: segment of every entry (from its first index; an empty list counts as segment 0) + per-block histogram
+__global__ __launch_bounds__(GRP_BLOCK) void ft_group_count(const int32_t *__restrict__ idx0,
+                                                            const int32_t *__restrict__ idx1, int batch, int nnz,
+                                                            int cols, int seg_cols, int nseg, int E,
+                                                            uint8_t *__restrict__ seg_of, int *__restrict__ blk_cnt) {
+    __shared__ int hist[256];
+    if ((int)threadIdx.x < nseg) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int e = blockIdx.x * GRP_BLOCK + threadIdx.x;
+    if (e < E) {
+        const int k = e >= batch ? 1 : 0, b = e - k * batch;
+        const int j = (k ? idx1 : idx0)[(size_t)b * nnz];
+        const int sg = (j >= 0 && j < cols) ? j / seg_cols : 0;
+        seg_of[e] = (uint8_t)sg;
+        atomicAdd(&hist[sg], 1);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nseg) blk_cnt[(size_t)blockIdx.x * nseg + threadIdx.x] = hist[threadIdx.x];
+}
+
+// pass 2 (one workgroup): exclusive scan in (segment major, block minor) order -> blk_cnt becomes each block's
+// write cursor per segment; chunk / item tables
+__global__ __launch_bounds__(256) void ft_group_scan(int *__restrict__ blk_cnt, int nblk, int nseg, int fwd_item,
+                                                     int g_ch, int4 *__restrict__ chunks, int4 *__restrict__ fitems,
+                                                     int4 *__restrict__ bitems, int *__restrict__ seg_items,
+                                                     int *__restrict__ counts) {
+    extern __shared__ __align__(16) int gl[];  // [nblk][nseg] counts -> exclusive prefixes
+    __shared__ int tot[256], seg_start[257], ch_start[257], fi_start[257], bi_start[257];
+    for (int i = threadIdx.x; i < nblk * nseg; i += blockDim.x) gl[i] = blk_cnt[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int sg = wave; sg < nseg; sg += nwaves) {
+        int run = 0;
+        for (int b0 = 0; b0 < nblk; b0 += 64) {
+            const int b = b0 + lane;
+            const int v = b < nblk ? gl[b * nseg + sg] : 0;
+            int incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(incl, o);
+                if (lane >= o) incl += up;
+            }
+            if (b < nblk) gl[b * nseg + sg] = run + incl - v;
+            run += __shfl(incl, 63);
+        }
+        if (lane == 0) tot[sg] = run;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0, c = 0, f = 0, bi = 0;
+        for (int sg = 0; sg < nseg; sg++) {
+            seg_start[sg] = a, ch_start[sg] = c, fi_start[sg] = f, bi_start[sg] = bi;
+            const int n = tot[sg], nc = (n + FT_CHUNK - 1) / FT_CHUNK;
+            a += n, c += nc, f += (n + fwd_item - 1) / fwd_item, bi += (nc + g_ch - 1) / g_ch;
+        }
+        seg_start[nseg] = a, ch_start[nseg] = c, fi_start[nseg] = f, bi_start[nseg] = bi;
+        counts[0] = f, counts[1] = bi, counts[2] = c, counts[3] = 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nblk * nseg; i += blockDim.x) blk_cnt[i] = gl[i] + seg_start[i % nseg];
+    for (int i = threadIdx.x; i <= nseg; i += blockDim.x) seg_items[i] = bi_start[i];
+    auto seg_of_slot = [&](const int *start, int i) {
+        int sg = 0;
+        while (sg + 1 < nseg && start[sg + 1] <= i) sg++;
+        return sg;
+    };
+    for (int i = threadIdx.x; i < ch_start[nseg]; i += blockDim.x) {
+        const int sg = seg_of_slot(ch_start, i), j = i - ch_start[sg];
+        chunks[i] = make_int4(sg, seg_start[sg] + j * FT_CHUNK, min(FT_CHUNK, tot[sg] - j * FT_CHUNK), 0);
+    }
+    for (int i = threadIdx.x; i < fi_start[nseg]; i += blockDim.x) {
+        const int sg = seg_of_slot(fi_start, i), j = i - fi_start[sg];
+        fitems[i] = make_int4(sg, seg_start[sg] + j * fwd_item, min(fwd_item, tot[sg] - j * fwd_item), 0);
+    }
+    for (int i = threadIdx.x; i < bi_start[nseg]; i += blockDim.x) {
+        const int sg = seg_of_slot(bi_start, i), j = i - bi_start[sg];
+        const int nc = ch_start[sg + 1] - ch_start[sg];
+        bitems[i] = make_int4(sg, ch_start[sg] + j * g_ch, min(g_ch, nc - j * g_ch), 0);
+    }
+}
+
+// pass 3: stable placement (ascending entry id inside a segment)
+__global__ __launch_bounds__(GRP_BLOCK) void ft_group_place(const uint8_t *__restrict__ seg_of,
+                                                            const int *__restrict__ blk_base, int nseg, int E,
+                                                            int *__restrict__ elist) {
+    __shared__ int wcnt[GRP_BLOCK / 64][256];
+    const int e = blockIdx.x * GRP_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sg = e < E ? (int)seg_of[e] : -1;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int rank = 0;
+    for (int s2 = 0; s2 < nseg; s2++) {
+        const unsigned long long m = __ballot(sg == s2);
+        if (sg == s2) rank = __popcll(m & lt_mask);
+        if (lane == 0) wcnt[wave][s2] = __popcll(m);
+    }
+    __syncthreads();
+    if (e < E) {
+        int pos = blk_base[(size_t)blockIdx.x * nseg + sg] + rank;
+        for (int w2 = 0; w2 < wave; w2++) pos += wcnt[w2][sg];
+        elist[pos] = e;
+    }
+}
+
 // ------------------------------------------------------------------ index build (shared by all backward paths)
 // One workgroup per chunk.  W waves; wave w owns the contiguous entry sub-range w of the chunk and a
 // private per-feature counter row, so the fill pass is race-free and stable without cross-wave ordering.
@@ -135,9 +260,12 @@ __global__ __launch_bounds__(256) void ft_fwd_generic(const float *__restrict__ 
 //   scan  : exclusive scan in (feature major, wave minor) order -> start[w][f]; offs[chunk][f] to global
 //   pass 2: each wave walks its entries in order, 64/nnz_pad entries per step; lanes with equal feature
 //           rank themselves by ballot (one ballot per feature-id bit) and take consecutive slots.
+// GRP: chunk c is a slice of the segment-grouped entry list; `cols` is the segment width, features are stored
+// relative to the segment, `cols_total` bounds the stop rule.
+template <bool GRP>
 __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t *__restrict__ idx1, int batch,
                                 int nnz, int cols, int chunks_per_input, int fbits, uint16_t *__restrict__ sorted,
-                                uint32_t *__restrict__ offs) {
+                                uint32_t *__restrict__ offs, FtGrp gp, int cols_total) {
     extern __shared__ uint32_t lds[];
     const int nwaves = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6;
@@ -146,11 +274,19 @@ __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t 
     uint32_t *tsum = lds + (size_t)nwaves * cols;  // [blockDim.x] scan scratch
 
     const int c = blockIdx.x;
-    const int k = c / chunks_per_input;
-    const int cb = c % chunks_per_input;
-    const int b0 = cb * FT_CHUNK;
-    const int n_e = min(FT_CHUNK, batch - b0);
-    const int32_t *idx = (k == 0 ? idx0 : idx1) + (size_t)b0 * nnz;
+    int n_e, col0 = 0, start0 = 0;
+    const int32_t *idx = nullptr;
+    if constexpr (GRP) {
+        if (c >= gp.counts[2]) return;
+        const int4 ch = gp.chunks[c];
+        col0 = ch.x * cols, start0 = ch.y, n_e = ch.z;
+    } else {
+        const int k = c / chunks_per_input;
+        const int cb = c % chunks_per_input;
+        const int b0 = cb * FT_CHUNK;
+        n_e = min(FT_CHUNK, batch - b0);
+        idx = (k == 0 ? idx0 : idx1) + (size_t)b0 * nnz;
+    }
     uint16_t *my_sorted = sorted + (size_t)c * ft_sorted_cap(nnz, cols);
     uint32_t *my_offs = offs + (size_t)c * (cols + 1);
 
@@ -171,31 +307,46 @@ __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t 
     // sub-ranges -- few waves or very short lists -- reload the rest from L2 in pass 2).
     constexpr int IDX_REG = 16;
     const int nsteps = (per_wave + eps - 1) / eps;
+    // index slot `li` of chunk-local entry e (callers guarantee e < e_hi, li < nnz)
+    auto load_j = [&](int e) -> int {
+        if constexpr (GRP) {
+            const int eid = gp.elist[start0 + e];
+            const int k2 = eid >= batch ? 1 : 0;
+            return (k2 ? idx1 : idx0)[(size_t)(eid - k2 * batch) * nnz + li];
+        } else {
+            return idx[(size_t)e * nnz + li];
+        }
+    };
     int jr[IDX_REG];
 #pragma unroll
     for (int st = 0; st < IDX_REG; st++) {
         const int e = e_lo + st * eps + sub;
-        jr[st] = (st < nsteps && e < e_hi && li < nnz) ? idx[(size_t)e * nnz + li] : -1;
+        jr[st] = (st < nsteps && e < e_hi && li < nnz) ? load_j(e) : -1;
     }
     const unsigned long long seg = (slot == 64) ? ~0ull : (((1ull << slot) - 1) << (sub * slot));
     // list length of this lane's entry: the first invalid index ends it (write.rs:231)
     auto n_valid = [&](int e, int j) {
-        const bool inval = (e < e_hi) && (li >= nnz || j < 0 || j >= cols);
+        const bool inval = (e < e_hi) && (li >= nnz || j < 0 || j >= cols_total);
         const unsigned long long m = __ballot(inval) & seg;
         return m ? (__ffsll((long long)m) - 1 - sub * slot) : slot;
     };
 
     // pass 1
+    // GRP: a listed index outside the entry's segment breaks the caller's promise: flagged, not counted
+    auto in_seg = [&](int jl) { return !GRP || (jl >= 0 && jl < cols); };
     auto count_step = [&](int e, int j) {
         const int nvalid = n_valid(e, j);
-        if (e < e_hi && li < nvalid) atomicAdd(&cnt[(size_t)wave * cols + j], 1u);
+        if (e < e_hi && li < nvalid) {
+            if (in_seg(j - col0)) atomicAdd(&cnt[(size_t)wave * cols + (j - col0)], 1u);
+            else if constexpr (GRP) atomicAdd(gp.viol, 1);
+        }
     };
 #pragma unroll
     for (int st = 0; st < IDX_REG; st++)
         if (st < nsteps) count_step(e_lo + st * eps + sub, jr[st]);
     for (int st = IDX_REG; st < nsteps; st++) {
         const int e = e_lo + st * eps + sub;
-        count_step(e, (e < e_hi && li < nnz) ? idx[(size_t)e * nnz + li] : -1);
+        count_step(e, (e < e_hi && li < nnz) ? load_j(e) : -1);
     }
     __syncthreads();
 
@@ -235,9 +386,10 @@ __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t 
     // pass 2
     uint32_t *start = cnt + (size_t)wave * cols;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    auto place_step = [&](int e, int j) {
-        const int nvalid = n_valid(e, j);
-        const bool active = (e < e_hi) && (li < nvalid);
+    auto place_step = [&](int e, int jraw) {
+        const int nvalid = n_valid(e, jraw);
+        const int j = jraw - col0;
+        const bool active = (e < e_hi) && (li < nvalid) && in_seg(j);
         // lanes holding the same feature
         unsigned long long peers = __ballot(active);
         for (int bit = 0; bit < fbits; bit++) {
@@ -257,7 +409,7 @@ __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t 
         if (st < nsteps) place_step(e_lo + st * eps + sub, jr[st]);
     for (int st = IDX_REG; st < nsteps; st++) {
         const int e = e_lo + st * eps + sub;
-        place_step(e, (e < e_hi && li < nnz) ? idx[(size_t)e * nnz + li] : -1);
+        place_step(e, (e < e_hi && li < nnz) ? load_j(e) : -1);
     }
 }
 
@@ -426,25 +578,38 @@ __device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lanes of
     return v;
 }
 
-template <bool PAIR, bool ALIGNED4, int NROUND, bool HEAD>
+// GRP (bt_ft_desc.segment): the workgroup is (row tile, forward item); the tile holds the item's segment of
+// `tc` columns, entries come from the grouped list, and one more LDS row (all NaN) receives the slots whose
+// index lies outside the segment, so a broken promise poisons the entry's output instead of passing silently.
+template <bool PAIR, bool ALIGNED4, int NROUND, bool HEAD, bool GRP>
 __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restrict__ w, const float *__restrict__ bias,
                                                           const int32_t *__restrict__ idx0,
                                                           const int32_t *__restrict__ idx1, float *__restrict__ out,
                                                           float *__restrict__ saved, bt_ft_desc d, int ntiles,
-                                                          int entries_per_wg, FtHeadSink hs) {
-    extern __shared__ __align__(16) float wl[];  // [(cols + 1)][32]; row `cols` is all zero (target of masked slots)
+                                                          int entries_per_wg, FtHeadSink hs, FtGrp gp) {
+    extern __shared__ __align__(16) float wl[];  // [(tc + 1)][32]; row `tc` is all zero (target of masked slots)
     constexpr int SS = fwd_strip_words(NROUND);
     constexpr int TW = PAIR ? 16 : 32;  // output columns per perspective covered by this row tile
+    constexpr int XR = GRP ? 2 : 1;     // extra rows behind the tile: zeros [, NaNs]
     const int rt = blockIdx.x % ntiles, grp = blockIdx.x / ntiles;
     const int half_rows = d.rows / 2;
-    for (int q = threadIdx.x; q < d.cols * 8; q += LDS_THREADS) {
+    const int tc = GRP ? gp.tile_cols : d.cols;
+    int col0 = 0, g_begin = 0, g_end = 0;
+    if constexpr (GRP) {
+        if (grp >= gp.counts[0]) return;
+        const int4 it = gp.items[grp];
+        col0 = it.x * tc, g_begin = it.y, g_end = it.y + it.z;
+    }
+    for (int q = threadIdx.x; q < tc * 8; q += LDS_THREADS) {
         const int f = q >> 3, s8 = q & 7;
-        const float4 v = *reinterpret_cast<const float4 *>(w + (size_t)f * d.stride + d.offset +
+        const float4 v = *reinterpret_cast<const float4 *>(w + (size_t)(col0 + f) * d.stride + d.offset +
                                                             tile_row(PAIR, rt, half_rows, s8 * 4));
         *reinterpret_cast<float4 *>(wl + f * LDS_RT + s8 * 4) = v;
     }
-    if (threadIdx.x < LDS_RT) wl[d.cols * LDS_RT + threadIdx.x] = 0.0f;
-    float *w1t = wl + (d.cols + 1) * LDS_RT + (LDS_THREADS / 64) * FWD_EPW * SS;  // HEAD: [n_inputs][w1_rows][TW]
+    if (threadIdx.x < LDS_RT) wl[tc * LDS_RT + threadIdx.x] = 0.0f;
+    if constexpr (GRP)
+        if (threadIdx.x < LDS_RT) wl[(tc + 1) * LDS_RT + threadIdx.x] = __int_as_float(0x7fc00000);
+    float *w1t = wl + (tc + XR) * LDS_RT + (LDS_THREADS / 64) * FWD_EPW * SS;  // HEAD: [n_inputs][w1_rows][TW]
     if constexpr (HEAD) {
         const int ow = PAIR ? half_rows : d.rows;
         for (int q = threadIdx.x; q < d.n_inputs * hs.w1_rows * TW; q += LDS_THREADS) {
@@ -460,7 +625,7 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
     const int sub = lane & 7, eslot = lane >> 3;
     int ge, gs;
     fwd_gather_slot(lane, ge, gs);
-    uint32_t *wstrip = reinterpret_cast<uint32_t *>(wl + (d.cols + 1) * LDS_RT) + wave * FWD_EPW * SS;
+    uint32_t *wstrip = reinterpret_cast<uint32_t *>(wl + (tc + XR) * LDS_RT) + wave * FWD_EPW * SS;
     uint32_t *dstrip = wstrip + eslot * SS;        // written by the decode map
     const uint32_t *strip = wstrip + ge * SS;      // read by the gather map
     const int row = tile_row(PAIR, rt, half_rows, gs * 4);
@@ -469,16 +634,20 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
     // entries e = k*batch + b as 32-bit ints (host checks n_inputs*batch < 2^30); n_inputs <= 2, so the
     // (k, b) split is a compare + subtract -- no integer division in the hot loop
     const int E = d.n_inputs * d.batch;
-    const int e_begin = grp * entries_per_wg;
-    const int e_end = min(E, e_begin + entries_per_wg);
+    const int e_begin = GRP ? g_begin : grp * entries_per_wg;
+    const int e_end = GRP ? g_end : min(E, e_begin + entries_per_wg);
     const int out_w = PAIR ? half_rows : d.rows;
     constexpr int PASS = (LDS_THREADS / 64) * FWD_EPW;
+    // entry id at list position `pos` (GRP: through the grouped list, clamped to the item)
+    auto ent = [&](int pos) -> int {
+        if constexpr (GRP) return gp.elist[min(pos, e_end - 1)];
+        else return min(pos, E - 1);
+    };
 
     // raw indices of the NEXT pass are loaded while the current one is being summed. Unconditional, clamped
     // loads (validity is applied at decode time): with no branch around them the compiler keeps them in
     // flight behind a counted s_waitcnt instead of draining with vmcnt(0).
-    auto load_idx = [&](int eb2, int(&r)[NROUND][4]) {
-        const int e2 = min(eb2 + eslot, E - 1);
+    auto load_idx = [&](int e2, int(&r)[NROUND][4]) {
         const int k2 = (e2 >= d.batch) ? 1 : 0;
         const int b2 = e2 - k2 * d.batch;
         const int32_t *ip = (k2 == 0 ? idx0 : idx1) + (size_t)b2 * d.nnz;
@@ -494,23 +663,41 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
         }
     };
     // HEAD: the bucket of this lane's gather-map entry, fetched one pass ahead like the indices
-    auto load_bucket = [&](int eb2) {
+    auto load_bucket = [&](int e2) {
         if (!HEAD || !hs.bucket) return 0;
-        const int e2 = min(eb2 + ge, E - 1);
         return (int)hs.bucket[e2 - ((e2 >= d.batch) ? d.batch : 0)];
     };
     int nxt[NROUND][4];
-    load_idx(e_begin + wave * FWD_EPW, nxt);
-    int nxt_bk = load_bucket(e_begin + wave * FWD_EPW);
-    for (int eb = e_begin + wave * FWD_EPW; eb < e_end; eb += PASS) {
+    const int eb0 = e_begin + wave * FWD_EPW;
+    // GRP: entry ids are fetched two passes ahead (decode map d1/d2, gather map g0/g1), so the index and bucket
+    // loads that depend on them are still issued one full pass before use
+    int d1 = 0, d2 = 0, g0 = 0, g1 = 0;
+    if constexpr (GRP) {
+        d1 = ent(eb0 + PASS + eslot), d2 = ent(eb0 + 2 * PASS + eslot);
+        g0 = ent(eb0 + ge), g1 = ent(eb0 + PASS + ge);
+    }
+    load_idx(ent(eb0 + eslot), nxt);
+    int nxt_bk = load_bucket(GRP ? g0 : ent(eb0 + ge));
+    for (int eb = eb0; eb < e_end; eb += PASS) {
         const int bk = nxt_bk;
-        nxt_bk = load_bucket(eb + PASS);
+        const int e_cur = GRP ? g0 : eb + ge;  // gather-map entry of this pass
+        if constexpr (GRP) {
+            nxt_bk = load_bucket(g1);
+            g0 = g1, g1 = ent(eb + 2 * PASS + ge);
+        } else {
+            nxt_bk = load_bucket(ent(eb + PASS + ge));
+        }
         int reg[NROUND][4];
 #pragma unroll
         for (int q = 0; q < NROUND; q++)
 #pragma unroll
             for (int j = 0; j < 4; j++) reg[q][j] = nxt[q][j];
-        load_idx(eb + PASS, nxt);
+        if constexpr (GRP) {
+            load_idx(d1, nxt);
+            d1 = d2, d2 = ent(eb + 3 * PASS + eslot);
+        } else {
+            load_idx(ent(eb + PASS + eslot), nxt);
+        }
         // decode: slot p is masked iff any slot <= p of the same entry is invalid
         bool dead = eb + eslot >= e_end;
         int nblk = 0;  // wave-uniform: 4-slot blocks that hold a live slot for at least one entry
@@ -528,10 +715,23 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
             bool kill = dead || (m & ((1u << sub) - 1u));
             const unsigned long long open = __ballot(!(kill || inv[0]));  // blocks whose first slot is live
             lds_u4_t o;
-            kill |= inv[0], o.x = (unsigned)(kill ? d.cols : reg[q][0]) * (LDS_RT * 4);
-            kill |= inv[1], o.y = (unsigned)(kill ? d.cols : reg[q][1]) * (LDS_RT * 4);
-            kill |= inv[2], o.z = (unsigned)(kill ? d.cols : reg[q][2]) * (LDS_RT * 4);
-            kill |= inv[3], o.w = (unsigned)(kill ? d.cols : reg[q][3]) * (LDS_RT * 4);
+            // live slot -> its tile row; GRP: outside the segment -> the NaN row (and the violation counter)
+            auto slot_row = [&](int j) -> unsigned {
+                if constexpr (GRP) {
+                    const int loc = j - col0;
+                    if (loc < 0 || loc >= tc) {
+                        atomicAdd(gp.viol, 1);
+                        return (unsigned)(tc + 1);
+                    }
+                    return (unsigned)loc;
+                } else {
+                    return (unsigned)j;
+                }
+            };
+            kill |= inv[0], o.x = (kill ? (unsigned)tc : slot_row(reg[q][0])) * (LDS_RT * 4);
+            kill |= inv[1], o.y = (kill ? (unsigned)tc : slot_row(reg[q][1])) * (LDS_RT * 4);
+            kill |= inv[2], o.z = (kill ? (unsigned)tc : slot_row(reg[q][2])) * (LDS_RT * 4);
+            kill |= inv[3], o.w = (kill ? (unsigned)tc : slot_row(reg[q][3])) * (LDS_RT * 4);
             *reinterpret_cast<lds_u4_t *>(dstrip + q * 32 + sub * 4) = o;
             dead |= (m != 0);
             unsigned fold = (unsigned)open | (unsigned)(open >> 32);
@@ -567,12 +767,15 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
             }
         }
         __builtin_amdgcn_wave_barrier();
-        const int e = eb + ge;
-        const bool live = e < e_end;
+        const int e = e_cur;
+        const bool live = eb + ge < e_end;
         const int k = (live && e >= d.batch) ? 1 : 0;
         const int b = live ? e - k * d.batch : 0;
         float4 c = make_float4(bt_act_fwd(d.act, acc.x + bv.x), bt_act_fwd(d.act, acc.y + bv.y),
                                bt_act_fwd(d.act, acc.z + bv.z), bt_act_fwd(d.act, acc.w + bv.w));
+        if constexpr (GRP) {  // a sum that met the NaN row stays NaN through the clamps of the activation
+            if (acc.x != acc.x) c = make_float4(acc.x, acc.x, acc.x, acc.x);
+        }
         if constexpr (PAIR) {
             // the lane holding part gs^4 of the same entry has the other factors of the same output columns
             const int partner = fwd_gather_lane(ge, gs ^ 4);
@@ -624,24 +827,34 @@ struct FtFusedSrc {
     int w1_rows;            // = number of output buckets (one output each)
 };
 
-template <bool PAIR, bool FUSED, int NSRT>
+// GRP (bt_ft_desc.segment): workgroup = (row tile, backward item); the dW tile covers the item's segment of `tc`
+// columns, chunks are slices of the grouped entry list (entry ids two chunks ahead in registers), and the item's
+// slab goes to partial_w[item][tc][stride] for ft_bwd_merge_grp.
+template <bool PAIR, bool FUSED, int NSRT, bool GRP>
 __device__ __forceinline__ void ft_bwd_lds_body(const float *__restrict__ grad_out, const FtFusedSrc &fs,
                                                 const float *__restrict__ out, const float *__restrict__ saved,
                                                 const uint16_t *__restrict__ sorted, const uint32_t *__restrict__ offs,
                                                 float *__restrict__ partial_w, float *__restrict__ partial_b,
                                                 const bt_ft_desc &d, int ntiles, int chunks_per_input,
-                                                int chunks_per_wg) {
+                                                int chunks_per_wg, const FtGrp &gp) {
     extern __shared__ __align__(16) float lds_f[];
-    float *acc = lds_f;                                   // [cols][32]
-    float *gt = acc + (size_t)d.cols * LDS_RT;            // [FT_CHUNK + 1][32], last row = zeros (padding target)
+    const int tc = GRP ? gp.tile_cols : d.cols;
+    float *acc = lds_f;                                   // [tc][32]
+    float *gt = acc + (size_t)tc * LDS_RT;                // [FT_CHUNK + 1][32], last row = zeros (padding target)
     uint16_t *srt = reinterpret_cast<uint16_t *>(gt + (FT_CHUNK + 1) * LDS_RT);    // [ft_sorted_cap]
-    uint16_t *blkf = srt + ft_sorted_cap(d.nnz, d.cols);                           // [ft_blk_cap] feature of each block
-    int *span = reinterpret_cast<int *>(blkf + ft_blk_cap(d.nnz, d.cols));         // [4] (2 used): widest run, in groups
+    uint16_t *blkf = srt + ft_sorted_cap(d.nnz, tc);                               // [ft_blk_cap] feature of each block
+    int *span = reinterpret_cast<int *>(blkf + ft_blk_cap(d.nnz, tc));             // [4] (2 used): widest run, in groups
     uint8_t *hrank = reinterpret_cast<uint8_t *>(span + 4);                        // [2][NGRP] rank of a group's head run
     float *w1t = reinterpret_cast<float *>(hrank + 2 * (LDS_THREADS / 8));          // FUSED: [n_inputs][w1_rows][TW]
     const int rt = blockIdx.x % ntiles, cg = blockIdx.x / ntiles;
     const int half_rows = d.rows / 2;
     const int nchunks = d.n_inputs * chunks_per_input;
+    int g_clo = 0, g_chi = 0;
+    if constexpr (GRP) {
+        if (cg >= gp.counts[1]) return;
+        const int4 it = gp.items[cg];
+        g_clo = it.y, g_chi = it.y + it.z;
+    }
     const int out_w = PAIR ? half_rows : d.rows;
     constexpr int TW = PAIR ? 16 : 32;  // output columns per perspective covered by this row tile
 
@@ -651,7 +864,7 @@ __device__ __forceinline__ void ft_bwd_lds_body(const float *__restrict__ grad_o
             w1t[q] = fs.w1[(size_t)(k * out_w + rt * TW + c) * fs.w1_rows + bk];
         }
     }
-    for (int q = threadIdx.x; q < d.cols * LDS_RT; q += LDS_THREADS) acc[q] = 0.0f;
+    for (int q = threadIdx.x; q < tc * LDS_RT; q += LDS_THREADS) acc[q] = 0.0f;
     if (threadIdx.x < LDS_RT) gt[FT_CHUNK * LDS_RT + threadIdx.x] = 0.0f;
 
     const int s8 = threadIdx.x & 7, el0 = threadIdx.x >> 3;  // staging role: 128 entries x 8 float4 per pass
@@ -663,7 +876,7 @@ __device__ __forceinline__ void ft_bwd_lds_body(const float *__restrict__ grad_o
     if (threadIdx.x < 4) span[threadIdx.x] = 0;
     if (threadIdx.x < 2 * NGRP) hrank[threadIdx.x] = 0;
     float4 bsum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const int c_lo = cg * chunks_per_wg, c_hi = min(nchunks, c_lo + chunks_per_wg);
+    const int c_lo = GRP ? g_clo : cg * chunks_per_wg, c_hi = GRP ? g_chi : min(nchunks, c_lo + chunks_per_wg);
     // Staging registers: the NEXT chunk's global loads are issued before the current chunk's LDS reduction
     // and consumed after it, so HBM latency overlaps the reduction without a second LDS buffer.
     constexpr int NPASS = FT_CHUNK / 128;
@@ -671,22 +884,60 @@ __device__ __forceinline__ void ft_bwd_lds_body(const float *__restrict__ grad_o
     // NSRT: uint4 rounds that cover the sorted list (host-checked)
     lds_u4_t r_srt[NSRT];  // (clang vector type: an array of HIP's uint4 struct ends up in scratch)
     uint32_t r_off[2], r_nblk = 0;
-    const int srt_cap = ft_sorted_cap(d.nnz, d.cols);
+    const int srt_cap = ft_sorted_cap(d.nnz, tc);
     const int srt_vec = srt_cap / 8;  // uint4 = 8 offsets
+    int r_eid[NPASS], r_ne = 0;  // GRP: entry ids of the NEXT chunk to prefetch; entries of the chunk being staged
+    const uint32_t t_col = PAIR ? rt * 16 + (s8 & 3) * 4 : rt * LDS_RT + s8 * 4;
+    auto load_eids = [&](int c) {
+        if constexpr (GRP) {
+            const int4 ch = gp.chunks[min(c, c_hi - 1)];
+#pragma unroll
+            for (int pass = 0; pass < NPASS; pass++) r_eid[pass] = gp.elist[ch.y + min(el0 + pass * 128, ch.z - 1)];
+        }
+    };
     // per-thread element offsets inside a chunk (32-bit; the chunk base is wave-uniform and lives in SGPRs)
     const uint32_t t_out = (uint32_t)el0 * d.out_ld + (PAIR ? rt * 16 + (s8 & 3) * 4 : rt * LDS_RT + s8 * 4);
     const uint32_t t_sav = (uint32_t)el0 * d.rows + rt * 16 + (s8 & 3) * 4;
     auto prefetch = [&](int c) {
+        if constexpr (GRP) {
+            const int n_e = gp.chunks[c].z;
+            r_ne = n_e;
+#pragma unroll
+            for (int pass = 0; pass < NPASS; pass++) {
+                const int el = el0 + pass * 128;
+                r_go[pass] = r_a[pass] = r_b[pass] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (el < n_e) {
+                    const int eid = r_eid[pass];
+                    const int k = eid >= d.batch ? 1 : 0, b = eid - k * d.batch;
+                    const size_t o_out = (size_t)b * d.out_ld + (size_t)k * out_w + t_col;
+                    if constexpr (FUSED) {
+                        r_go[pass].x = fs.gz[b];
+                        r_go[pass].y = __int_as_float(fs.bucket ? fs.bucket[b] : 0);
+                        r_go[pass].z = __int_as_float(k);
+                    } else {
+                        r_go[pass] = *reinterpret_cast<const float4 *>(grad_out + o_out);
+                    }
+                    if constexpr (PAIR) {
+                        const float *sv = saved + (size_t)eid * d.rows + rt * 16 + (s8 & 3) * 4;
+                        r_a[pass] = *reinterpret_cast<const float4 *>(sv);
+                        r_b[pass] = *reinterpret_cast<const float4 *>(sv + half_rows);
+                    } else {
+                        r_a[pass] = *reinterpret_cast<const float4 *>(out + o_out);
+                    }
+                }
+            }
+            load_eids(c + 1);
+        }
         const int k = c / chunks_per_input, cb = c % chunks_per_input;
         const int b0 = cb * FT_CHUNK;
-        const int n_e = min(FT_CHUNK, d.batch - b0);
+        const int n_e = GRP ? 0 : min(FT_CHUNK, d.batch - b0);
         const float *go_base = grad_out + (size_t)b0 * d.out_ld + (size_t)k * out_w;
         const float *out_base = out + (size_t)b0 * d.out_ld + (size_t)k * out_w;
         const float *sav_base = saved + ((size_t)k * d.batch + b0) * d.rows;
 #pragma unroll
         for (int pass = 0; pass < NPASS; pass++) {
             const int el = el0 + pass * 128;
-            r_go[pass] = r_a[pass] = r_b[pass] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if constexpr (!GRP) r_go[pass] = r_a[pass] = r_b[pass] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (el < n_e) {
                 if constexpr (FUSED) {
                     r_go[pass].x = fs.gz[b0 + el];
@@ -703,11 +954,11 @@ __device__ __forceinline__ void ft_bwd_lds_body(const float *__restrict__ grad_o
                 }
             }
         }
-        const uint32_t *go_ = offs + (size_t)c * (d.cols + 1);
+        const uint32_t *go_ = offs + (size_t)c * (tc + 1);
         // thread f keeps the bounds of feature f's run (r_off); features beyond 1024 take a second round below
-        r_off[0] = go_[min((int)threadIdx.x, d.cols)];
-        r_off[1] = go_[min((int)threadIdx.x + 1, d.cols)];
-        r_nblk = go_[d.cols] >> 2;
+        r_off[0] = go_[min((int)threadIdx.x, tc)];
+        r_off[1] = go_[min((int)threadIdx.x + 1, tc)];
+        r_nblk = go_[tc] >> 2;
         const lds_u4_t *gs = reinterpret_cast<const lds_u4_t *>(sorted + (size_t)c * srt_cap);
 #pragma unroll
         for (int i = 0; i < NSRT; i++) {
@@ -718,12 +969,15 @@ __device__ __forceinline__ void ft_bwd_lds_body(const float *__restrict__ grad_o
 #ifdef BT_EXP_TIMING
     unsigned long long t_last = __builtin_readcyclecounter();
 #endif
-    if (c_lo < c_hi) prefetch(c_lo);
+    if (c_lo < c_hi) {
+        load_eids(c_lo);
+        prefetch(c_lo);
+    }
     BT_T(0);
     for (int c = c_lo; c < c_hi; c++) {
         const int cb = c % chunks_per_input;
         const int kc = c / chunks_per_input;
-        const int n_e = min(FT_CHUNK, d.batch - cb * FT_CHUNK);
+        const int n_e = GRP ? r_ne : min(FT_CHUNK, d.batch - cb * FT_CHUNK);
         __syncthreads();  // previous chunk's readers are done with gt / srt / blkf
         BT_T(1);
 #pragma unroll
@@ -734,8 +988,9 @@ __device__ __forceinline__ void ft_bwd_lds_body(const float *__restrict__ grad_o
                 if constexpr (FUSED) {
                     const float gzv = go.x;
                     const int bk = __float_as_int(go.y);
+                    const int ke = GRP ? __float_as_int(go.z) : kc;  // the entry's input (perspective)
                     const float4 wv = *reinterpret_cast<const float4 *>(
-                        w1t + (kc * fs.w1_rows + bk) * TW + (PAIR ? (s8 & 3) : s8) * 4);
+                        w1t + (ke * fs.w1_rows + bk) * TW + (PAIR ? (s8 & 3) : s8) * 4);
                     go = make_float4(gzv * wv.x, gzv * wv.y, gzv * wv.z, gzv * wv.w);
                 }
                 float4 g;
@@ -760,9 +1015,9 @@ __device__ __forceinline__ void ft_bwd_lds_body(const float *__restrict__ grad_o
         const float rcp_q = 1.0f / (float)q;  // block -> group by a float multiply (exact: both < 2^12)
         int *cur_span = span + (c & 1);
         uint8_t *cur_rank = hrank + (c & 1) * NGRP;
-        for (int f = threadIdx.x, rnd = 0; f < d.cols; f += LDS_THREADS, rnd++) {
+        for (int f = threadIdx.x, rnd = 0; f < tc; f += LDS_THREADS, rnd++) {
             uint32_t o0 = r_off[0], o1 = r_off[1];
-            if (rnd > 0) o0 = offs[(size_t)c * (d.cols + 1) + f], o1 = offs[(size_t)c * (d.cols + 1) + f + 1];
+            if (rnd > 0) o0 = offs[(size_t)c * (tc + 1) + f], o1 = offs[(size_t)c * (tc + 1) + f + 1];
             const int sb = (int)(o0 >> 2), eb = (int)(o1 >> 2);
             for (int i = sb; i < eb; i++) blkf[i] = (uint16_t)f;
             if (eb > sb) {
@@ -876,8 +1131,8 @@ __device__ __forceinline__ void ft_bwd_lds_body(const float *__restrict__ grad_o
     BT_T(6);
     __syncthreads();
     BT_T(7);
-    float *pw = partial_w + (size_t)cg * d.cols * d.stride;
-    for (int q = threadIdx.x; q < d.cols * 8; q += LDS_THREADS) {
+    float *pw = partial_w + (size_t)cg * tc * d.stride;
+    for (int q = threadIdx.x; q < tc * 8; q += LDS_THREADS) {
         const int f = q >> 3, t8 = q & 7;
         *reinterpret_cast<float4 *>(pw + (size_t)f * d.stride + d.offset + tile_row(PAIR, rt, half_rows, t8 * 4)) =
             *reinterpret_cast<const float4 *>(acc + f * LDS_RT + t8 * 4);
@@ -900,11 +1155,11 @@ __global__ __launch_bounds__(LDS_THREADS) __attribute__((amdgpu_waves_per_eu(5, 
     const float *__restrict__ grad_out, FtFusedSrc fs, const float *__restrict__ out, const float *__restrict__ saved,
     const uint16_t *__restrict__ sorted, const uint32_t *__restrict__ offs, float *__restrict__ partial_w,
     float *__restrict__ partial_b, bt_ft_desc d, int ntiles, int chunks_per_input, int chunks_per_wg) {
-    ft_bwd_lds_body<false, FUSED, 2>(grad_out, fs, out, saved, sorted, offs, partial_w, partial_b, d, ntiles,
-                                     chunks_per_input, chunks_per_wg);
+    ft_bwd_lds_body<false, FUSED, 2, false>(grad_out, fs, out, saved, sorted, offs, partial_w, partial_b, d, ntiles,
+                                            chunks_per_input, chunks_per_wg, FtGrp{});
 }
 
-template <bool PAIR, bool FUSED>
+template <bool PAIR, bool FUSED, bool GRP>
 __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds_any(const float *__restrict__ grad_out, FtFusedSrc fs,
                                                               const float *__restrict__ out,
                                                               const float *__restrict__ saved,
@@ -912,9 +1167,37 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds_any(const float *__res
                                                               const uint32_t *__restrict__ offs,
                                                               float *__restrict__ partial_w,
                                                               float *__restrict__ partial_b, bt_ft_desc d, int ntiles,
-                                                              int chunks_per_input, int chunks_per_wg) {
-    ft_bwd_lds_body<PAIR, FUSED, 3>(grad_out, fs, out, saved, sorted, offs, partial_w, partial_b, d, ntiles,
-                                    chunks_per_input, chunks_per_wg);
+                                                              int chunks_per_input, int chunks_per_wg, FtGrp gp) {
+    ft_bwd_lds_body<PAIR, FUSED, 3, GRP>(grad_out, fs, out, saved, sorted, offs, partial_w, partial_b, d, ntiles,
+                                         chunks_per_input, chunks_per_wg, gp);
+}
+
+// segment-grouped merge: dw[seg*tc + f] = sum over the segment's backward items of their slabs (item order = list
+// order, fixed); a segment without entries gets zeros; dbias = sum over all items
+__global__ __launch_bounds__(256) void ft_bwd_merge_grp(const float *__restrict__ partial_w,
+                                                        const float *__restrict__ partial_b, float *__restrict__ dw,
+                                                        float *__restrict__ dbias, bt_ft_desc d, int tc,
+                                                        const int *__restrict__ seg_items,
+                                                        const int *__restrict__ counts) {
+    const int rows4 = d.rows / 4;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nw = (long long)d.cols * rows4;
+    if (t < nw) {
+        const int f = (int)(t / rows4), r = (int)(t % rows4) * 4;
+        const int sg = f / tc, fl = f - sg * tc;
+        const size_t o = (size_t)fl * d.stride + d.offset + r;
+        float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int g = seg_items[sg]; g < seg_items[sg + 1]; g++) {
+            const float4 v = *reinterpret_cast<const float4 *>(partial_w + (size_t)g * tc * d.stride + o);
+            s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(dw + (size_t)f * d.stride + d.offset + r) = s;
+    } else if (dbias && t < nw + d.rows) {
+        const int r = (int)(t - nw), G = counts[1];
+        float s = 0.0f;
+        for (int g = 0; g < G; g++) s += partial_b[(size_t)g * d.rows + r];
+        dbias[r] = s;
+    }
 }
 
 // dw[f][offset + r] = sum_g partial_w[g][f][offset + r] (fixed order); dbias likewise
@@ -952,7 +1235,16 @@ struct FtPlan {
     int fbits;
     size_t off_sorted, off_offs, off_g, off_bpart, total;
     int bias_blocks;
+    // segment-grouped mode (bt_ft_desc.segment): tc = tile columns (= segment, else cols)
+    bool grouped;
+    int tc, nseg, grp_blocks, max_chunks, max_fitems, max_bitems, fwd_item, g_ch;
+    size_t off_segof, off_blkcnt, off_elist, off_chunks, off_fitems, off_bitems, off_counts, off_segitems;
 };
+
+int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e && e[0] ? atoi(e) : dflt;
+}
 
 int ft_validate(const bt_ft_desc *d, const char *who) {
     BT_REQUIRE(d, "%s: null descriptor", who);
@@ -965,6 +1257,7 @@ int ft_validate(const bt_ft_desc *d, const char *who) {
     BT_REQUIRE(!d->pairwise || d->rows % 2 == 0, "%s: pairwise needs even rows", who);
     const int out_w = d->pairwise ? d->rows / 2 : d->rows;
     BT_REQUIRE(d->out_ld >= d->n_inputs * out_w, "%s: Mismatched sizes! (out_ld < n_inputs*out_w)", who);
+    BT_REQUIRE(d->segment >= 0 && (d->segment == 0 || d->cols % d->segment == 0), "%s: segment must divide cols", who);
     return BT_OK;
 }
 
@@ -973,38 +1266,82 @@ int ft_vec(const bt_ft_desc *d) {
     return (out_w % 4 == 0 && d->stride % 4 == 0 && d->offset % 4 == 0 && d->out_ld % 4 == 0 && d->rows % 4 == 0) ? 4 : 1;
 }
 
+size_t ft_lds_fwd_bytes(const bt_ft_desc *d, int tc, bool grouped) {
+    return (size_t)(tc + (grouped ? 2 : 1)) * LDS_RT * sizeof(float) +
+           (size_t)(LDS_THREADS / 64) * FWD_EPW * fwd_strip_words((d->nnz + 31) / 32) * sizeof(uint32_t);
+}
+size_t ft_lds_bwd_bytes(const bt_ft_desc *d, int tc) {
+    return ((size_t)tc * LDS_RT + (FT_CHUNK + 1) * LDS_RT) * sizeof(float) +
+           (size_t)ft_sorted_cap(d->nnz, tc) * sizeof(uint16_t) + (size_t)ft_blk_cap(d->nnz, tc) * sizeof(uint16_t) +
+           4 * sizeof(int) + 2 * (LDS_THREADS / 8);
+}
+bool ft_lds_fits(const bt_ft_desc *d, int tc, bool grouped) {
+    return ft_vec(d) == 4 && d->rows % LDS_RT == 0 && ft_lds_bwd_bytes(d, tc) <= 160 * 1024 &&
+           ft_lds_fwd_bytes(d, tc, grouped) <= 160 * 1024 && ft_sorted_cap(d->nnz, tc) / 8 <= 3 * LDS_THREADS;
+}
+
 int ft_plan(const bt_ft_desc *d, FtPlan *p) {
     p->vec = ft_vec(d);
+    // Segment-grouped mode: only when the whole table does not fit the LDS kernels but one segment does (and the
+    // index lists allow the aligned single-round forward); otherwise `segment` is ignored.
+    const long long E = (long long)d->n_inputs * d->batch;
+    p->nseg = d->segment > 0 ? d->cols / d->segment : 1;
+    p->grouped = d->segment > 0 && p->nseg > 1 && p->nseg <= 256 && !force_generic() &&
+                 (!ft_lds_fits(d, d->cols, false) || env_int("BT_FT_FORCE_GROUPED", 0)) &&
+                 ft_lds_fits(d, d->segment, true) && d->nnz % 4 == 0 && d->nnz <= 32 &&
+                 (size_t)bt_div_up(E, GRP_BLOCK) * p->nseg * sizeof(int) <= 128 * 1024;
+    p->tc = p->grouped ? d->segment : d->cols;
     p->chunks_per_input = bt_div_up(d->batch, FT_CHUNK);
-    p->nchunks = p->chunks_per_input * d->n_inputs;
+    p->nchunks = p->grouped ? bt_div_up(E, FT_CHUNK) + p->nseg : p->chunks_per_input * d->n_inputs;
+    p->max_chunks = p->nchunks;
     // LDS budget for the index kernel: nwaves*cols + 64*nwaves words
     int wv = 8;
-    while (wv > 1 && ((size_t)wv * d->cols + 64 * wv) * 4 > 150 * 1024) wv >>= 1;
-    BT_REQUIRE(((size_t)wv * d->cols + 64 * wv) * 4 <= 150 * 1024, "bt_ft_backward: cols=%d too large", d->cols);
+    while (wv > 1 && ((size_t)wv * p->tc + 64 * wv) * 4 > 150 * 1024) wv >>= 1;
+    BT_REQUIRE(((size_t)wv * p->tc + 64 * wv) * 4 <= 150 * 1024, "bt_ft_backward: cols=%d too large", d->cols);
     p->index_waves = wv;
     p->fbits = 1;
-    while ((1 << p->fbits) < d->cols) p->fbits++;
+    while ((1 << p->fbits) < p->tc) p->fbits++;
     size_t o = 0;
     p->off_sorted = o;
-    o += bt_align((size_t)p->nchunks * ft_sorted_cap(d->nnz, d->cols) * sizeof(uint16_t));
+    o += bt_align((size_t)p->nchunks * ft_sorted_cap(d->nnz, p->tc) * sizeof(uint16_t));
     p->off_offs = o;
-    o += bt_align((size_t)p->nchunks * (d->cols + 1) * sizeof(uint32_t));
+    o += bt_align((size_t)p->nchunks * (p->tc + 1) * sizeof(uint32_t));
     p->off_g = o;
     o += bt_align((size_t)d->n_inputs * d->batch * d->rows * sizeof(float));
     p->bias_blocks = bt_div_up((long long)d->n_inputs * d->batch, 256);
     p->off_bpart = o;
     o += bt_align((size_t)p->bias_blocks * d->rows * sizeof(float));
     // LDS-resident path: 32-row tiles, table tile + staging must fit the 160 KiB LDS
-    p->lds_fwd_bytes = (size_t)(d->cols + 1) * LDS_RT * sizeof(float) +
-                       (size_t)(LDS_THREADS / 64) * FWD_EPW * fwd_strip_words((d->nnz + 31) / 32) * sizeof(uint32_t);
-    p->lds_bwd_bytes = ((size_t)d->cols * LDS_RT + (FT_CHUNK + 1) * LDS_RT) * sizeof(float) +
-                       (size_t)ft_sorted_cap(d->nnz, d->cols) * sizeof(uint16_t) +
-                       (size_t)ft_blk_cap(d->nnz, d->cols) * sizeof(uint16_t) + 4 * sizeof(int) + 2 * (LDS_THREADS / 8);
-    p->lds_path = (p->vec == 4) && (d->rows % LDS_RT == 0) && p->lds_bwd_bytes <= 160 * 1024 &&
-                  p->lds_fwd_bytes <= 160 * 1024 && ft_sorted_cap(d->nnz, d->cols) / 8 <= 3 * LDS_THREADS;
+    p->lds_fwd_bytes = ft_lds_fwd_bytes(d, p->tc, p->grouped);
+    p->lds_bwd_bytes = ft_lds_bwd_bytes(d, p->tc);
+    p->lds_path = ft_lds_fits(d, p->tc, p->grouped);
     p->ntiles = d->rows / LDS_RT;
     p->G = 1, p->chunks_per_wg = p->nchunks;
-    if (p->lds_path) {
+    if (p->grouped) {
+        // item sizes: ~1024 / ntiles forward items and ~768 / ntiles backward items per launch, so the grid has a
+        // few workgroups per CU and no item is more than a fraction of a CU's share
+        const int tgt_f = std::max(1, 1024 / p->ntiles), tgt_b = std::max(1, 768 / p->ntiles);
+        int fi = (int)std::min<long long>(4096, std::max<long long>(128, (E / tgt_f + 127) / 128 * 128));
+        int gc = std::max(1, std::min(16, p->max_chunks / tgt_b));
+        p->fwd_item = env_int("BT_FT_FWD_ITEM", fi), p->g_ch = env_int("BT_FT_BWD_CHUNKS", gc);
+        p->fwd_item = std::max(128, p->fwd_item / 128 * 128), p->g_ch = std::max(1, p->g_ch);
+        p->grp_blocks = bt_div_up(E, GRP_BLOCK);
+        p->max_fitems = bt_div_up(E, p->fwd_item) + p->nseg;
+        p->max_bitems = bt_div_up(p->max_chunks, p->g_ch) + p->nseg;
+        p->G = p->max_bitems;
+        p->off_pw = o;
+        o += bt_align((size_t)p->max_bitems * p->tc * d->stride * sizeof(float));
+        p->off_pb = o;
+        o += bt_align((size_t)p->max_bitems * d->rows * sizeof(float));
+        p->off_segof = o, o += bt_align((size_t)E);
+        p->off_blkcnt = o, o += bt_align((size_t)p->grp_blocks * p->nseg * sizeof(int));
+        p->off_elist = o, o += bt_align((size_t)E * sizeof(int));
+        p->off_chunks = o, o += bt_align((size_t)p->max_chunks * sizeof(int4));
+        p->off_fitems = o, o += bt_align((size_t)p->max_fitems * sizeof(int4));
+        p->off_bitems = o, o += bt_align((size_t)p->max_bitems * sizeof(int4));
+        p->off_counts = o, o += bt_align(8 * sizeof(int));
+        p->off_segitems = o, o += bt_align((size_t)(p->nseg + 1) * sizeof(int));
+    } else if (p->lds_path) {
         int G = 256 / p->ntiles;
         if (G < 1) G = 1;
         if (G > p->nchunks) G = p->nchunks;
@@ -1026,6 +1363,15 @@ int set_lds(K kernel, size_t bytes) {
     return BT_OK;
 }
 
+// the group tables inside a workspace; `fwd` selects which item list the kernels walk
+FtGrp ft_grp(const FtPlan &p, char *ws, bool fwd) {
+    if (!p.grouped) return FtGrp{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    int *counts = reinterpret_cast<int *>(ws + p.off_counts);
+    return FtGrp{reinterpret_cast<const int *>(ws + p.off_elist),
+                 reinterpret_cast<const int4 *>(ws + (fwd ? p.off_fitems : p.off_bitems)),
+                 reinterpret_cast<const int4 *>(ws + p.off_chunks), counts, counts + 3, p.tc};
+}
+
 int ft_backward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, const float *grad_out, FtFusedSrc fs,
                            const float *out, const float *saved, const uint16_t *sorted, const uint32_t *offs, char *ws,
                            float *dw, float *dbias) {
@@ -1033,28 +1379,49 @@ int ft_backward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, 
     dim3 grid(p.ntiles * p.G), block(LDS_THREADS);
     const bool fused = fs.gz != nullptr;
     const size_t lds = p.lds_bwd_bytes + (fused ? (size_t)d->n_inputs * fs.w1_rows * 32 * sizeof(float) : 0);
-    const bool lean = !d->pairwise && ft_sorted_cap(d->nnz, d->cols) / 8 <= 2 * LDS_THREADS;
+    const bool lean = !p.grouped && !d->pairwise && ft_sorted_cap(d->nnz, d->cols) / 8 <= 2 * LDS_THREADS;
+    const FtGrp gp = ft_grp(p, ws, false);
+    const int cpi = p.grouped ? 1 : p.chunks_per_input;
 #define BWD_LDS(KERNEL)                                                                                             \
     do {                                                                                                            \
         if (int rc = set_lds(KERNEL, lds)) return rc;                                                               \
         BT_LAUNCH(BTK_FT_BWD_LDS, s, (KERNEL), grid, block, lds, grad_out, fs, out, saved, sorted, offs, pw, pb, *d,  \
-                  p.ntiles, p.chunks_per_input, p.chunks_per_wg);                                                   \
+                  p.ntiles, cpi, p.chunks_per_wg);                                                                  \
+    } while (0)
+#define BWD_ANY(KERNEL)                                                                                             \
+    do {                                                                                                            \
+        if (int rc = set_lds(KERNEL, lds)) return rc;                                                               \
+        BT_LAUNCH(BTK_FT_BWD_LDS, s, (KERNEL), grid, block, lds, grad_out, fs, out, saved, sorted, offs, pw, pb, *d,  \
+                  p.ntiles, cpi, p.chunks_per_wg, gp);                                                              \
     } while (0)
     if (lean) {
         if (fused) BWD_LDS(ft_bwd_lds<true>);
         else BWD_LDS(ft_bwd_lds<false>);
+    } else if (p.grouped) {
+        if (d->pairwise) {
+            if (fused) BWD_ANY((ft_bwd_lds_any<true, true, true>));
+            else BWD_ANY((ft_bwd_lds_any<true, false, true>));
+        } else {
+            if (fused) BWD_ANY((ft_bwd_lds_any<false, true, true>));
+            else BWD_ANY((ft_bwd_lds_any<false, false, true>));
+        }
     } else if (d->pairwise) {
-        if (fused) BWD_LDS((ft_bwd_lds_any<true, true>));
-        else BWD_LDS((ft_bwd_lds_any<true, false>));
+        if (fused) BWD_ANY((ft_bwd_lds_any<true, true, false>));
+        else BWD_ANY((ft_bwd_lds_any<true, false, false>));
     } else {
-        if (fused) BWD_LDS((ft_bwd_lds_any<false, true>));
-        else BWD_LDS((ft_bwd_lds_any<false, false>));
+        if (fused) BWD_ANY((ft_bwd_lds_any<false, true, false>));
+        else BWD_ANY((ft_bwd_lds_any<false, false, false>));
     }
 #undef BWD_LDS
+#undef BWD_ANY
     BT_LAUNCH_CHECK();
     if (d->rows != d->stride) BT_HIP(hipMemsetAsync(dw, 0, (size_t)d->stride * d->cols * sizeof(float), s));
     const long long n = (long long)d->cols * (d->rows / 4) + d->rows;
-    BT_LAUNCH(BTK_FT_BWD_MERGE, s, ft_bwd_merge, dim3(bt_div_up(n, 256)), dim3(256), 0, pw, pb, dw, dbias, *d, p.G);
+    if (p.grouped)
+        BT_LAUNCH(BTK_FT_BWD_MERGE, s, ft_bwd_merge_grp, dim3(bt_div_up(n, 256)), dim3(256), 0, pw, pb, dw, dbias, *d, p.tc,
+                  reinterpret_cast<const int *>(ws + p.off_segitems), reinterpret_cast<const int *>(ws + p.off_counts));
+    else
+        BT_LAUNCH(BTK_FT_BWD_MERGE, s, ft_bwd_merge, dim3(bt_div_up(n, 256)), dim3(256), 0, pw, pb, dw, dbias, *d, p.G);
     BT_LAUNCH_CHECK();
     return BT_OK;
 }
@@ -1091,7 +1458,8 @@ size_t ft_head_lds_bytes(const bt_ft_desc *d, int head_rows) {
 }
 
 int ft_forward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, const float *w, const float *bias,
-                          const int32_t *i0, const int32_t *i1, float *out, float *saved, const FtHeadSink *head) {
+                          const int32_t *i0, const int32_t *i1, float *out, float *saved, const FtHeadSink *head,
+                          char *ws = nullptr) {
     const long long E = (long long)d->n_inputs * d->batch;
     int G = 256 / p.ntiles;
     if (G < 1) G = 1;
@@ -1104,11 +1472,33 @@ int ft_forward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, c
     dim3 lgrid(p.ntiles * G), lblock(LDS_THREADS);
     const FtHeadSink hs = head ? *head : FtHeadSink{nullptr, nullptr, 0, nullptr};
     const size_t lds = p.lds_fwd_bytes + (head ? ft_head_lds_bytes(d, hs.w1_rows) : 0);
+    if (p.grouped) {
+        BT_REQUIRE(ws, "bt_ft_forward: segment-grouped forward needs the workspace of bt_ft_build_index");
+        BT_REQUIRE(al4, "bt_ft_forward: segment-grouped forward needs 16-byte aligned index lists");
+        const FtGrp gp = ft_grp(p, ws, true);
+        dim3 ggrid(p.ntiles * p.max_fitems);
+#define FWD_GRP(PAIR, HEAD)                                                                                         \
+    do {                                                                                                            \
+        if (int rc = set_lds(ft_fwd_lds<PAIR, true, 1, HEAD, true>, lds)) return rc;                                \
+        BT_LAUNCH(BTK_FT_FWD_LDS, s, (ft_fwd_lds<PAIR, true, 1, HEAD, true>), ggrid, lblock, lds, w, bias, i0, i1, out, \
+                  saved, *d, p.ntiles, 0, hs, gp);                                                                  \
+    } while (0)
+        if (d->pairwise) {
+            if (head) FWD_GRP(true, true);
+            else FWD_GRP(true, false);
+        } else {
+            if (head) FWD_GRP(false, true);
+            else FWD_GRP(false, false);
+        }
+#undef FWD_GRP
+        BT_LAUNCH_CHECK();
+        return BT_OK;
+    }
 #define FWD_LDS(PAIR, AL4, NROUND, HEAD)                                                                           \
     do {                                                                                                           \
-        if (int rc = set_lds(ft_fwd_lds<PAIR, AL4, NROUND, HEAD>, lds)) return rc;                                 \
-        BT_LAUNCH(BTK_FT_FWD_LDS, s, (ft_fwd_lds<PAIR, AL4, NROUND, HEAD>), lgrid, lblock, lds, w, bias, i0, i1, out, \
-                  saved, *d, p.ntiles, (int)epw, hs);                                                              \
+        if (int rc = set_lds(ft_fwd_lds<PAIR, AL4, NROUND, HEAD, false>, lds)) return rc;                          \
+        BT_LAUNCH(BTK_FT_FWD_LDS, s, (ft_fwd_lds<PAIR, AL4, NROUND, HEAD, false>), lgrid, lblock, lds, w, bias, i0, i1, \
+                  out, saved, *d, p.ntiles, (int)epw, hs, FtGrp{});                                                \
     } while (0)
 #define FWD_LDS3(PAIR, AL4, NROUND)                                                                                \
     do {                                                                                                           \
@@ -1148,7 +1538,8 @@ int bt_internal_ft_head_parts(const bt_ft_desc *d) { return d->n_inputs * (d->ro
 
 int bt_internal_ft_forward_head(void *stream, const bt_ft_desc *d, const float *w, const float *bias,
                                 const int32_t *const *idx, float *out, float *saved, const float *w1,
-                                const int32_t *bucket, int head_rows, float *zpart) {
+                                const int32_t *bucket, int head_rows, float *zpart, void *workspace,
+                                size_t workspace_bytes) {
     if (int rc = ft_validate(d, "bt_ft_forward")) return rc;
     BT_REQUIRE(w && idx && idx[0] && out && w1 && zpart, "bt_ft_forward(head): null pointer");
     BT_REQUIRE(d->n_inputs == 1 || idx[1], "bt_ft_forward: null index pointer for input 1");
@@ -1156,9 +1547,74 @@ int bt_internal_ft_forward_head(void *stream, const bt_ft_desc *d, const float *
     BT_REQUIRE(bt_internal_ft_forward_head_ok(d, head_rows), "bt_ft_forward(head): shape not supported");
     FtPlan p;
     if (int rc = ft_plan(d, &p)) return rc;
+    BT_REQUIRE(!p.grouped || (workspace && workspace_bytes >= p.total), "bt_ft_forward(head): workspace too small");
     const FtHeadSink hs{w1, bucket, head_rows, zpart};
     return ft_forward_lds_launch(bt_stream(stream), d, p, w, bias, idx[0], d->n_inputs > 1 ? idx[1] : idx[0], out, saved,
-                                 &hs);
+                                 &hs, static_cast<char *>(workspace));
+}
+
+// ---- internal: the two halves of bt_ft_build_index. The entry lists (segment-grouped tables only) are needed by
+// the forward pass, the per-chunk sorted lists only by the backward pass, so net.hip puts them on different streams.
+int bt_internal_ft_build_groups(void *stream, const bt_ft_desc *d, const int32_t *const *idx, void *workspace,
+                                size_t workspace_bytes) {
+    if (int rc = ft_validate(d, "bt_ft_build_index")) return rc;
+    BT_REQUIRE(idx && idx[0] && workspace, "bt_ft_build_index: null pointer");
+    BT_REQUIRE(d->n_inputs == 1 || idx[1], "bt_ft_build_index: null index pointer for input 1");
+    FtPlan p;
+    if (int rc = ft_plan(d, &p)) return rc;
+    BT_REQUIRE(workspace_bytes >= p.total, "bt_ft_build_index: workspace too small (%zu < %zu)", workspace_bytes, p.total);
+    if (!p.grouped) return BT_OK;
+    hipStream_t s = bt_stream(stream);
+    char *ws = static_cast<char *>(workspace);
+    const int32_t *i0 = idx[0], *i1 = d->n_inputs > 1 ? idx[1] : idx[0];
+    const int E = d->n_inputs * d->batch;
+    uint8_t *seg_of = reinterpret_cast<uint8_t *>(ws + p.off_segof);
+    int *blk = reinterpret_cast<int *>(ws + p.off_blkcnt);
+    BT_LAUNCH(BTK_FT_INDEX, s, ft_group_count, dim3(p.grp_blocks), dim3(GRP_BLOCK), 0, i0, i1, d->batch, d->nnz, d->cols,
+              p.tc, p.nseg, E, seg_of, blk);
+    BT_LAUNCH_CHECK();
+    const size_t lds = (size_t)p.grp_blocks * p.nseg * sizeof(int);
+    if (int rc = set_lds(ft_group_scan, lds)) return rc;
+    BT_LAUNCH(BTK_FT_INDEX, s, ft_group_scan, dim3(1), dim3(256), lds, blk, p.grp_blocks, p.nseg, p.fwd_item, p.g_ch,
+              reinterpret_cast<int4 *>(ws + p.off_chunks), reinterpret_cast<int4 *>(ws + p.off_fitems),
+              reinterpret_cast<int4 *>(ws + p.off_bitems), reinterpret_cast<int *>(ws + p.off_segitems),
+              reinterpret_cast<int *>(ws + p.off_counts));
+    BT_LAUNCH_CHECK();
+    BT_LAUNCH(BTK_FT_INDEX, s, ft_group_place, dim3(p.grp_blocks), dim3(GRP_BLOCK), 0, seg_of, blk, p.nseg, E,
+              reinterpret_cast<int *>(ws + p.off_elist));
+    BT_LAUNCH_CHECK();
+    return BT_OK;
+}
+
+int bt_internal_ft_build_sorted(void *stream, const bt_ft_desc *d, const int32_t *const *idx, void *workspace,
+                                size_t workspace_bytes) {
+    if (int rc = ft_validate(d, "bt_ft_build_index")) return rc;
+    BT_REQUIRE(idx && idx[0] && workspace, "bt_ft_build_index: null pointer");
+    BT_REQUIRE(d->n_inputs == 1 || idx[1], "bt_ft_build_index: null index pointer for input 1");
+    FtPlan p;
+    if (int rc = ft_plan(d, &p)) return rc;
+    BT_REQUIRE(workspace_bytes >= p.total, "bt_ft_build_index: workspace too small (%zu < %zu)", workspace_bytes, p.total);
+    hipStream_t s = bt_stream(stream);
+    char *ws = static_cast<char *>(workspace);
+    uint16_t *sorted = reinterpret_cast<uint16_t *>(ws + p.off_sorted);
+    uint32_t *offs = reinterpret_cast<uint32_t *>(ws + p.off_offs);
+    const int32_t *i0 = idx[0], *i1 = d->n_inputs > 1 ? idx[1] : idx[0];
+    const int threads = p.index_waves * 64;
+    const size_t lds = ((size_t)p.index_waves * p.tc + threads) * sizeof(uint32_t);
+    const FtGrp gp = ft_grp(p, ws, false);
+    if (p.grouped)
+        BT_LAUNCH(BTK_FT_INDEX, s, ft_index_kernel<true>, dim3(p.nchunks), dim3(threads), lds, i0, i1, d->batch, d->nnz,
+                  p.tc, 1, p.fbits, sorted, offs, gp, d->cols);
+    else
+        BT_LAUNCH(BTK_FT_INDEX, s, ft_index_kernel<false>, dim3(p.nchunks), dim3(threads), lds, i0, i1, d->batch, d->nnz,
+                  d->cols, p.chunks_per_input, p.fbits, sorted, offs, gp, d->cols);
+    BT_LAUNCH_CHECK();
+    return BT_OK;
+}
+
+bool bt_internal_ft_grouped(const bt_ft_desc *d) {
+    FtPlan p;
+    return !ft_validate(d, "ft_grouped") && !ft_plan(d, &p) && p.grouped;
 }
 
 #ifdef BT_EXP_TIMING2
@@ -1192,7 +1648,9 @@ int bt_ft_forward(void *stream, const bt_ft_desc *d, const float *w, const float
     const int32_t *i0 = idx[0], *i1 = d->n_inputs > 1 ? idx[1] : idx[0];
     FtPlan p;
     if (int rc = ft_plan(d, &p)) return rc;
-    if (p.lds_path && !force_generic()) return ft_forward_lds_launch(s, d, p, w, bias, i0, i1, out, saved, nullptr);
+    // (segment-grouped tables need the entry lists: bt_ft_forward_prebuilt; here they take the any-shape kernel)
+    if (p.lds_path && !p.grouped && !force_generic())
+        return ft_forward_lds_launch(s, d, p, w, bias, i0, i1, out, saved, nullptr);
     if (vec == 4) {
         if (d->pairwise)
             BT_LAUNCH(BTK_FT_FWD_GENERIC, s, (ft_fwd_generic<4, true>), grid, block, 0, w, bias, i0, i1, out, saved, *d);
@@ -1223,16 +1681,35 @@ int bt_ft_build_index(void *stream, const bt_ft_desc *d, const int32_t *const *i
     FtPlan p;
     if (int rc = ft_plan(d, &p)) return rc;
     BT_REQUIRE(workspace_bytes >= p.total, "bt_ft_build_index: workspace too small (%zu < %zu)", workspace_bytes, p.total);
-    hipStream_t s = bt_stream(stream);
-    char *ws = static_cast<char *>(workspace);
-    uint16_t *sorted = reinterpret_cast<uint16_t *>(ws + p.off_sorted);
-    uint32_t *offs = reinterpret_cast<uint32_t *>(ws + p.off_offs);
-    const int32_t *i0 = idx[0], *i1 = d->n_inputs > 1 ? idx[1] : idx[0];
-    const int threads = p.index_waves * 64;
-    const size_t lds = ((size_t)p.index_waves * d->cols + threads) * sizeof(uint32_t);
-    BT_LAUNCH(BTK_FT_INDEX, s, ft_index_kernel, dim3(p.nchunks), dim3(threads), lds, i0, i1, d->batch, d->nnz, d->cols,
-              p.chunks_per_input, p.fbits, sorted, offs);
-    BT_LAUNCH_CHECK();
+    if (int rc = bt_internal_ft_build_groups(stream, d, idx, workspace, workspace_bytes)) return rc;
+    return bt_internal_ft_build_sorted(stream, d, idx, workspace, workspace_bytes);
+}
+
+int bt_ft_forward_prebuilt(void *stream, const bt_ft_desc *d, const float *w, const float *bias,
+                           const int32_t *const *idx, float *out, float *saved, void *workspace, size_t workspace_bytes) {
+    if (int rc = ft_validate(d, "bt_ft_forward")) return rc;
+    FtPlan p;
+    if (int rc = ft_plan(d, &p)) return rc;
+    if (!p.grouped) return bt_ft_forward(stream, d, w, bias, idx, out, saved);
+    BT_REQUIRE(w && idx && idx[0] && out && workspace, "bt_ft_forward: null pointer");
+    BT_REQUIRE(d->n_inputs == 1 || idx[1], "bt_ft_forward: null index pointer for input 1");
+    BT_REQUIRE(!d->pairwise || saved, "bt_ft_forward: pairwise needs a `saved` buffer");
+    BT_REQUIRE(workspace_bytes >= p.total, "bt_ft_forward: workspace too small (%zu < %zu)", workspace_bytes, p.total);
+    return ft_forward_lds_launch(bt_stream(stream), d, p, w, bias, idx[0], d->n_inputs > 1 ? idx[1] : idx[0], out, saved,
+                                 nullptr, static_cast<char *>(workspace));
+}
+
+int bt_ft_segment_violations(void *stream, const bt_ft_desc *d, void *workspace, size_t workspace_bytes, int *count) {
+    if (int rc = ft_validate(d, "bt_ft_segment_violations")) return rc;
+    BT_REQUIRE(workspace && count, "bt_ft_segment_violations: null pointer");
+    FtPlan p;
+    if (int rc = ft_plan(d, &p)) return rc;
+    *count = 0;
+    if (!p.grouped) return BT_OK;
+    BT_REQUIRE(workspace_bytes >= p.total, "bt_ft_segment_violations: workspace too small");
+    BT_HIP(hipMemcpyAsync(count, static_cast<char *>(workspace) + p.off_counts + 3 * sizeof(int), sizeof(int),
+                          hipMemcpyDeviceToHost, bt_stream(stream)));
+    BT_HIP(hipStreamSynchronize(bt_stream(stream)));
     return BT_OK;
 }
 

@@ -53,6 +53,8 @@ int net_validate(const bt_net_desc *d) {
     BT_REQUIRE(d->n_dense >= 1 && d->n_dense <= BT_MAX_DENSE, "bt_net: n_dense out of range");
     BT_REQUIRE(d->num_buckets >= 1, "bt_net: num_buckets must be >= 1");
     BT_REQUIRE(!d->pairwise || d->ft_out % 2 == 0, "bt_net: pairwise needs even ft_out");
+    BT_REQUIRE(d->ft_segment >= 0 && (d->ft_segment == 0 || d->num_inputs % d->ft_segment == 0),
+               "bt_net: ft_segment must divide num_inputs");
     BT_REQUIRE(d->loss_kind >= BT_LOSS_SIGMOID_MSE && d->loss_kind <= BT_LOSS_SOFTMAX_CE, "bt_net: unknown loss kind");
     if (d->loss_kind == BT_LOSS_SOFTMAX_CE)
         BT_REQUIRE(d->dense_out[d->n_dense - 1] >= 2, "bt_net: softmax cross-entropy needs >= 2 outputs per bucket");
@@ -95,6 +97,7 @@ bt_ft_desc ft_desc(const bt_net *n, int batch) {
     f.batch = batch, f.rows = d.ft_out, f.cols = d.num_inputs, f.stride = d.ft_out, f.offset = 0, f.nnz = d.nnz;
     f.act = d.ft_act, f.pairwise = d.pairwise, f.n_inputs = d.perspectives;
     f.out_ld = dense_in(&d, 0);
+    f.segment = d.ft_segment;
     return f;
 }
 bt_dense_desc dn_desc(const bt_net *n, int k, int batch) {
@@ -199,19 +202,24 @@ int check_batch(const bt_net *net, const bt_batch *b, const char *who) {
     return BT_OK;
 }
 
+// groups_ready: the segment entry lists of this batch are already in ft_ws (bt_net_forward_backward builds them
+// before it forks the side stream); otherwise they are built here, in stream order
 int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bool want_gz0 = false,
-                 bool head_in_ft = false) {
+                 bool head_in_ft = false, bool groups_ready = false) {
     bt_ft_desc f = ft_desc(n, b->batch);
     const int32_t *idx[2] = {b->stm, b->nstm};
     const float *w0 = nullptr;
     if (int rc = ft_weights(n, s, &w0)) return rc;
+    if (!groups_ready)
+        if (int rc = bt_internal_ft_build_groups(s, &f, idx, n->ft_ws, n->ft_ws_bytes)) return rc;
     if (head_in_ft) {
         // single one-output layer: its dot products are formed inside the FT forward, tile by tile, and a small
         // finishing kernel adds the partials, the bias, the loss and its gradient
         bt_dense_desc q = dn_desc(n, 0, b->batch);
         const int32_t *bk = n->d.dense_bucketed[0] ? b->buckets : nullptr;
         if (int rc = bt_internal_ft_forward_head(s, &f, w0, n->params + n->t_off[1], idx, n->hid,
-                                                 n->saved, n->params + n->t_off[2], bk, q.buckets, n->zpart))
+                                                 n->saved, n->params + n->t_off[2], bk, q.buckets, n->zpart, n->ft_ws,
+                                                 n->ft_ws_bytes))
             return rc;
         // Cross-stream packets cost a few us of bubble each on this stream. The index join goes here, between the FT
         // forward and the finishing kernel (it has long been satisfied), and "forward done" (ev_fwd) rides on the
@@ -222,7 +230,9 @@ int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bo
                                        b->targets, n->d.use_entry_weights ? b->entry_weights : nullptr, n->a[0],
                                        n->grad_y, want_gz0 ? n->gz0 : nullptr, n->loss_partials, &n->n_loss_partials);
     }
-    if (int rc = bt_ft_forward(s, &f, w0, n->params + n->t_off[1], idx, n->hid, n->saved)) return rc;
+    if (int rc = bt_ft_forward_prebuilt(s, &f, w0, n->params + n->t_off[1], idx, n->hid, n->saved, n->ft_ws,
+                                        n->ft_ws_bytes))
+        return rc;
     const float *x = n->hid;
     for (int k = 0; k < n->d.n_dense; k++) {
         bt_dense_desc q = dn_desc(n, k, b->batch);
@@ -420,10 +430,12 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
     hipStream_t s = bt_stream(stream);
     bt_ft_desc f = ft_desc(n, b->batch);
     const int32_t *idx[2] = {b->stm, b->nstm};
-    // fork: index build on the side stream, ordered after everything already queued on `s`
+    // segment-grouped tables: the entry lists are needed by the forward pass too, so they are built on `s` first
+    if (int rc = bt_internal_ft_build_groups(s, &f, idx, n->ft_ws, n->ft_ws_bytes)) return rc;
+    // fork: sorted index build on the side stream, ordered after everything already queued on `s`
     BT_HIP(hipEventRecord(n->ev_fork, s));
     BT_HIP(hipStreamWaitEvent(n->side, n->ev_fork, 0));
-    if (int rc = bt_ft_build_index(n->side, &f, idx, n->ft_ws, n->ft_ws_bytes)) return rc;
+    if (int rc = bt_internal_ft_build_sorted(n->side, &f, idx, n->ft_ws, n->ft_ws_bytes)) return rc;
     BT_HIP(hipEventRecord(n->ev_index, n->side));
     const int L = n->d.n_dense;
     // fusion decisions (shape-dependent, see dense.hip / ft.hip): loss into the final head's forward, the head's dX
@@ -437,7 +449,7 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
     // HBM-bound in a small-footprint kernel shape, the other LDS-bound, and they share the CUs.
     const bool side_head = fuse_loss && fuse_ft && L == 1;
     const bool head_in_ft = side_head && bt_internal_ft_forward_head_ok(&f, q0.buckets) && b->batch <= 1024 * 64;
-    if (int rc = forward_impl(n, s, b, fuse_loss, side_head, head_in_ft)) return rc;
+    if (int rc = forward_impl(n, s, b, fuse_loss, side_head, head_in_ft, true)) return rc;
     if (!fuse_loss)
         if (int rc = bt_loss(s, n->d.loss_kind, b->batch, n->d.dense_out[L - 1], net_output(n), b->targets,
                              n->d.use_entry_weights ? b->entry_weights : nullptr, n->d.loss_power, loss_sum_dev,

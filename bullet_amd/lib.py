@@ -18,7 +18,8 @@ class BtError(RuntimeError):
 
 class FtDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in
-                ("batch", "rows", "cols", "stride", "offset", "nnz", "act", "pairwise", "n_inputs", "out_ld")]
+                ("batch", "rows", "cols", "stride", "offset", "nnz", "act", "pairwise", "n_inputs", "out_ld",
+                 "segment")]
 
 
 class DenseDesc(C.Structure):
@@ -38,7 +39,7 @@ class NetDesc(C.Structure):
         ("dense_out", C.c_int * MAX_DENSE), ("dense_act", C.c_int * MAX_DENSE),
         ("dense_bucketed", C.c_int * MAX_DENSE), ("use_entry_weights", C.c_int),
         ("ft_factoriser", C.c_int), ("dense_dual", C.c_int * MAX_DENSE), ("dense_skip", C.c_int * MAX_DENSE),
-        ("loss_kind", C.c_int), ("loss_power", C.c_float),
+        ("ft_segment", C.c_int), ("loss_kind", C.c_int), ("loss_power", C.c_float),
     ]
 
 
@@ -122,7 +123,7 @@ SYMBOLS = [
     "bt_memset_async", "bt_memcpy_h2d_async", "bt_memcpy_d2h_async", "bt_memcpy_d2d_async",
     "bt_profile_start", "bt_profile_set_filter", "bt_profile_stop", "bt_profile_num_kernels", "bt_profile_kernel_name",
     "bt_ft_forward", "bt_ft_backward_workspace_bytes", "bt_ft_backward", "bt_ft_build_index",
-    "bt_ft_backward_prebuilt",
+    "bt_ft_backward_prebuilt", "bt_ft_forward_prebuilt", "bt_ft_segment_violations",
     "bt_dense_forward", "bt_dense_backward_workspace_bytes", "bt_dense_backward",
     "bt_sigmoid_mse", "bt_loss", "bt_adamw", "bt_radam", "bt_lookahead", "bt_weight_clip", "bt_weight_decay",
     "bt_net_set_optimiser",
@@ -171,6 +172,11 @@ def load():
     L.bt_ft_backward_workspace_bytes.argtypes = [C.POINTER(FtDesc)]
     L.bt_ft_backward.argtypes = [C.c_void_p, C.POINTER(FtDesc), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.bt_ft_build_index.argtypes = [C.c_void_p, C.POINTER(FtDesc), C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t]
+    L.bt_ft_backward_prebuilt.argtypes = [C.c_void_p, C.POINTER(FtDesc)] + [C.c_void_p] * 6 + [C.c_size_t]
+    L.bt_ft_forward_prebuilt.argtypes = [C.c_void_p, C.POINTER(FtDesc), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.bt_ft_segment_violations.argtypes = [C.c_void_p, C.POINTER(FtDesc), C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
     L.bt_dense_forward.argtypes = [C.c_void_p, C.POINTER(DenseDesc)] + [C.c_void_p] * 5
     L.bt_dense_backward_workspace_bytes.argtypes = [C.POINTER(DenseDesc)]
     L.bt_dense_backward.argtypes = [C.c_void_p, C.POINTER(DenseDesc)] + [C.c_void_p] * 9 + [C.c_size_t]
@@ -248,7 +254,8 @@ def profile_stop():
 
 
 def make_net_desc(num_inputs, nnz, ft_out, ft_act, dense, pairwise=False, perspectives=2, num_buckets=1,
-                  use_entry_weights=False, ft_factoriser=0, loss="sigmoid_mse", loss_power=2.0):
+                  use_entry_weights=False, ft_factoriser=0, loss="sigmoid_mse", loss_power=2.0,
+                  ft_segment=0):
     """dense: list of (out_per_bucket, act_name, bucketed[, dual[, skip]]); ft_factoriser = NB repeats of l0f;
     loss: "sigmoid_mse" | "sigmoid_power" (with loss_power) | "softmax_ce" (last layer = classes per bucket)"""
     d = NetDesc()
@@ -262,6 +269,7 @@ def make_net_desc(num_inputs, nnz, ft_out, ft_act, dense, pairwise=False, perspe
     d.use_entry_weights = int(use_entry_weights)
     d.ft_factoriser = ft_factoriser
     d.loss_kind, d.loss_power = LOSS[loss], float(loss_power)
+    d.ft_segment = ft_segment
     return d
 
 

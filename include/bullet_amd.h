@@ -110,6 +110,13 @@ typedef struct {
     int n_inputs; /* 1 or 2 sparse inputs sharing W                                */
     int out_ld;   /* floats per position in `out`; input k occupies columns [k*out_w, (k+1)*out_w),
                      out_w = pairwise ? rows/2 : rows                              */
+    int segment;  /* 0, or the width of a column segment that holds ALL active features of any one
+                     (position, input): 768 for the king-bucketed input sets, whose indices are
+                     768*bucket[ksq] + piece-square (chess_buckets.rs:28-33,82-88). Tables too large for the
+                     LDS-resident kernels are then processed segment by segment through them
+                     (bt_ft_forward_prebuilt / bt_ft_backward*). It is a promise about the data: an index
+                     outside its entry's segment sets a device flag (bt_ft_segment_violations) and turns that
+                     entry's forward output into NaN instead of being summed. Must divide cols. */
 } bt_ft_desc;
 
 /* w: F32[stride*cols] column-major (docs/4-saved-networks.md:21-29); bias: F32[rows] or NULL;
@@ -139,6 +146,13 @@ int bt_ft_build_index(void *stream, const bt_ft_desc *desc, const int32_t *const
                       size_t workspace_bytes);
 int bt_ft_backward_prebuilt(void *stream, const bt_ft_desc *desc, const float *grad_out, const float *out,
                             const float *saved, float *dw, float *dbias, void *workspace, size_t workspace_bytes);
+/* bt_ft_forward for descriptors with `segment` set: runs on the entry lists bt_ft_build_index left in the
+ * workspace (same stream order: build first). Without `segment` it is bt_ft_forward. */
+int bt_ft_forward_prebuilt(void *stream, const bt_ft_desc *desc, const float *w, const float *bias,
+                           const int32_t *const *idx, float *out, float *saved, void *workspace, size_t workspace_bytes);
+/* synchronises the stream and returns how many indices bt_ft_build_index / the segment kernels found outside
+ * their entry's segment since the index was built (0 = the promise held) */
+int bt_ft_segment_violations(void *stream, const bt_ft_desc *desc, void *workspace, size_t workspace_bytes, int *count);
 
 /* Dense affine layer with optional output-bucket select and activation:
  * Matmul (linear/matmul.rs:62-93, lowered model/operations/linear.rs:128-149, device
@@ -236,6 +250,8 @@ typedef struct {
     int dense_skip[BT_MAX_DENSE]; /* s: the last s outputs of layer k are sliced off and added to the net output
                                      (slice_rows + `out + skip_neuron`, test2.rs:54-64); next layer sees
                                      (dense_out - s) * (dual ? 2 : 1) inputs */
+    int ft_segment;               /* bt_ft_desc.segment for the feature transformer (768 for ChessBuckets /
+                                     ChessBucketsMirrored inputs without the Factorised wrapper; 0 = none) */
     int loss_kind;                /* BT_LOSS_* (0 = sigmoid MSE). BT_LOSS_SOFTMAX_CE: the last layer has dense_out = number
                                      of classes (3 for wdl_output, value/builder.rs:133) and targets are
                                      F32[batch * classes] */

@@ -44,10 +44,36 @@ def ft_forward(desc, w, bias, idxs, pairwise_saved=False):
     dw, db = dev(w), (dev(bias) if bias is not None else None)
     di = [dev(i) for i in idxs]
     ptrs = (C.c_void_p * 2)(*[t.data_ptr() for t in di] + [None] * (2 - len(di)))
-    lib.check(L.bt_ft_forward(stream(), C.byref(desc), dw.data_ptr(), db.data_ptr() if db is not None else None, ptrs,
-                              out.data_ptr(), saved.data_ptr() if saved is not None else None))
+    if desc.segment > 0:  # segment-grouped tables: entry lists first, then the forward that walks them
+        wsb = L.bt_ft_backward_workspace_bytes(C.byref(desc))
+        assert wsb > 0, L.bt_last_error()
+        ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+        lib.check(L.bt_ft_build_index(stream(), C.byref(desc), ptrs, ws.data_ptr(), wsb))
+        lib.check(L.bt_ft_forward_prebuilt(stream(), C.byref(desc), dw.data_ptr(),
+                                           db.data_ptr() if db is not None else None, ptrs, out.data_ptr(),
+                                           saved.data_ptr() if saved is not None else None, ws.data_ptr(), wsb))
+        viol = C.c_int(-1)
+        lib.check(L.bt_ft_segment_violations(stream(), C.byref(desc), ws.data_ptr(), wsb, C.byref(viol)))
+        ft_forward.last_violations = viol.value
+    else:
+        lib.check(L.bt_ft_forward(stream(), C.byref(desc), dw.data_ptr(), db.data_ptr() if db is not None else None,
+                                  ptrs, out.data_ptr(), saved.data_ptr() if saved is not None else None))
     torch.cuda.synchronize()
     return out.cpu().numpy(), (saved.cpu().numpy() if saved is not None else None)
+
+
+def segment_indices(rng, batch, nnz, nseg, seg_cols, seg_probs=None, min_cnt=0):
+    """index lists whose valid prefix stays inside one segment per entry (king-bucketed input sets); the stale tail
+    behind the -1 terminator may point anywhere"""
+    idx = np.empty((batch, nnz), dtype=np.int32)
+    segs = rng.choice(nseg, size=batch, p=seg_probs)
+    for b in range(batch):
+        cnt = int(rng.integers(min_cnt, nnz + 1))
+        idx[b, :cnt] = segs[b] * seg_cols + rng.choice(seg_cols, size=cnt, replace=False)
+        if cnt < nnz:
+            idx[b, cnt] = -1
+            idx[b, cnt + 1:] = rng.integers(-1, nseg * seg_cols, size=nnz - cnt - 1)
+    return idx
 
 
 def ft_backward(desc, idxs, grad_out, out, saved, want_bias=True):

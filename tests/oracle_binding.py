@@ -75,8 +75,9 @@ def vp(a):
 
 
 def make_net(num_inputs, nnz, ft_out, ft_act, dense, pairwise=False, perspectives=2, num_buckets=1,
-             use_entry_weights=False, ft_factoriser=0, loss="sigmoid_mse", loss_power=2.0):
-    """dense: list of (out_per_bucket, act_name, bucketed[, dual[, skip]])"""
+             use_entry_weights=False, ft_factoriser=0, loss="sigmoid_mse", loss_power=2.0, ft_segment=0):
+    """dense: list of (out_per_bucket, act_name, bucketed[, dual[, skip]]); ft_segment is a layout promise to the
+    device kernels and changes nothing in the arithmetic, so the oracle ignores it"""
     d = NetDesc()
     d.num_inputs, d.nnz, d.ft_out, d.ft_act = num_inputs, nnz, ft_out, ACT[ft_act]
     d.pairwise, d.perspectives, d.num_buckets, d.n_dense = int(pairwise), perspectives, num_buckets, len(dense)

@@ -139,6 +139,13 @@ NETS = {
 }
 
 
+# the king-bucketed nets again with the segment promise (ft_segment = 768): entry lists + the LDS-resident kernels
+# per (row tile, king bucket), including the fused head forward / backward of the single-layer net
+for _n in ("cfg3_multilayer", "test2_factoriser_dual_skip", "factoriser_single_layer"):
+    _cfg, _inp, _nb, _eff = NETS[_n]
+    NETS[_n + "_segment"] = (dict(_cfg, ft_segment=768), _inp, _nb, _eff)
+
+
 @pytest.mark.parametrize("name", list(NETS))
 def test_net_step_vs_oracle(name):
     cfg, (kind, layout, fact), nb, ft_eff = NETS[name]
@@ -146,7 +153,7 @@ def test_net_step_vs_oracle(name):
     if cfg.get("use_entry_weights"):
         rng = np.random.default_rng(1)
         batches = [(s, n, b, t, (rng.random(t.shape[0]) + 0.5).astype(np.float32)) for s, n, b, t, _ in batches]
-    r = run_steps(cfg, batches, 4, ft_eff=ft_eff, clip=[0] if name == "cfg3_multilayer" else None)
+    r = run_steps(cfg, batches, 4, ft_eff=ft_eff, clip=[0] if name.startswith("cfg3_multilayer") else None)
     dg, og = r["first_grads"]
     for t, (a, b) in enumerate(zip(dg, og)):
         scale = max(float(np.abs(b).max()), 1e-6)

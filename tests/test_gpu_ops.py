@@ -121,6 +121,73 @@ def test_ft_forward_backward_vs_oracle(ft_path, batch, rows, cols, nnz, act, pai
     assert np.array_equal(dw3, 2 * dw)
 
 
+SEG_CASES = [
+    # batch rows seg nseg nnz act pairwise n_inputs stride offset skew
+    (700, 64, 768, 4, 32, "crelu", 1, 2, 64, 0, False),      # pairwise, 4 king buckets
+    (1500, 128, 768, 16, 32, "screlu", 0, 2, 128, 0, True),  # HalfKA-16 shape, skewed buckets, some empty
+    (2100, 32, 768, 10, 32, "screlu", 0, 1, 96, 32, True),   # single input, sliced weights (stride/offset)
+    (520, 64, 64, 8, 8, "relu", 0, 2, 64, 0, False),         # small segments (whole table would fit: forced)
+]
+
+
+@pytest.mark.parametrize("batch,rows,seg,nseg,nnz,act,pairwise,n_inputs,stride,offset,skew", SEG_CASES)
+def test_ft_segment_grouped_vs_oracle(monkeypatch, batch, rows, seg, nseg, nnz, act, pairwise, n_inputs, stride, offset,
+                                      skew):
+    """bt_ft_desc.segment: tables too large for LDS processed segment by segment (entry lists + the LDS kernels).
+    Same bars as the ungrouped kernels: forward keeps the per-element summation order, backward is a batch sum."""
+    monkeypatch.setenv("BT_FT_FORCE_GROUPED", "1")
+    monkeypatch.setenv("BT_FT_FWD_ITEM", "256")   # several forward / backward items per segment at this batch size
+    monkeypatch.setenv("BT_FT_BWD_CHUNKS", "2")
+    rng = np.random.default_rng(batch + rows)
+    cols = seg * nseg
+    out_w = rows // 2 if pairwise else rows
+    d = lib.FtDesc(batch=batch, rows=rows, cols=cols, stride=stride, offset=offset, nnz=nnz, act=lib.ACT[act],
+                   pairwise=pairwise, n_inputs=n_inputs, out_ld=n_inputs * out_w, segment=seg)
+    w = (rng.standard_normal(stride * cols) * 0.2).astype(np.float32)
+    bias = (rng.standard_normal(rows) * 0.3).astype(np.float32)
+    probs = None
+    if skew:
+        probs = np.zeros(nseg)
+        probs[[0, 1, nseg - 1]] = [0.6, 0.3, 0.1]  # most segments empty, one holding 60 % of the entries
+    idxs = [gu.segment_indices(rng, batch, nnz, nseg, seg, probs) for _ in range(n_inputs)]
+    idxs[0][0, :] = -1  # an empty position
+    idxs[0][1, :] = (nseg - 1) * seg + rng.choice(seg, size=nnz, replace=False)  # a full one (no terminator)
+    idxs[0][2, 0] = cols  # out-of-range first index terminates the (empty) list
+    out, saved = gu.ft_forward(d, w, bias, idxs)
+    assert gu.ft_forward.last_violations == 0
+    ref_out, ref_saved = gu.oracle_ft_forward(d, w, bias, idxs)
+    gu.assert_close(out, ref_out, rtol=2e-6, atol=1e-6, what="ft out")
+    if pairwise:
+        gu.assert_close(saved, ref_saved, rtol=2e-6, atol=1e-6, what="ft saved")
+    grad_out = rng.standard_normal((batch, d.out_ld)).astype(np.float32)
+    dw, db = gu.ft_backward(d, idxs, grad_out, ref_out, ref_saved)
+    ref_dw, ref_db, gs = gu.oracle_ft_backward(d, idxs, grad_out, ref_out, ref_saved)
+    scale = float(np.abs(np.concatenate(gs)).max()) * np.sqrt(batch * n_inputs)
+    gu.assert_close(dw, ref_dw, rtol=1e-5, atol=2e-6 * scale, what="dW")
+    gu.assert_close(db, ref_db, rtol=1e-5, atol=2e-6 * scale, what="dbias")
+    dw2, db2 = gu.ft_backward(d, idxs, grad_out, ref_out, ref_saved)
+    assert np.array_equal(dw, dw2) and np.array_equal(db, db2)  # bit-identical run to run
+    # the same table without the promise (any-shape kernels): same numbers within the summation-order bar
+    d0 = lib.FtDesc(batch=batch, rows=rows, cols=cols, stride=stride, offset=offset, nnz=nnz, act=lib.ACT[act],
+                    pairwise=pairwise, n_inputs=n_inputs, out_ld=n_inputs * out_w, segment=0)
+    out0, _ = gu.ft_forward(d0, w, bias, idxs)
+    assert np.array_equal(out0, out)  # forward: identical order => identical bits
+
+
+def test_ft_segment_promise_violation_is_loud(monkeypatch):
+    """an index outside its entry's segment: counted on the device and the entry's output turns into NaN"""
+    monkeypatch.setenv("BT_FT_FORCE_GROUPED", "1")
+    rng = np.random.default_rng(5)
+    d = lib.FtDesc(batch=300, rows=32, cols=4 * 768, stride=32, offset=0, nnz=32, act=lib.ACT["crelu"], pairwise=0,
+                   n_inputs=1, out_ld=32, segment=768)
+    w = rng.standard_normal(32 * d.cols).astype(np.float32)
+    idx = gu.segment_indices(rng, 300, 32, 4, 768, min_cnt=4)
+    idx[17, 2] = (idx[17, 0] // 768 * 768 + 768 + 5) % d.cols  # third feature of position 17 from another segment
+    out, _ = gu.ft_forward(d, w, None, [idx])
+    assert gu.ft_forward.last_violations >= 1
+    assert np.isnan(out[17]).all() and not np.isnan(np.delete(out, 17, axis=0)).any()
+
+
 DENSE_CASES = [(777, 2048, 1, 8, "identity"), (300, 1024, 16, 8, "screlu"), (300, 16, 32, 8, "screlu"),
                (300, 32, 1, 8, "identity"), (1000, 64, 1, 1, "identity"), (50, 512, 1, 1, "identity"),
                (33, 20, 3, 2, "crelu"), (300, 8, 3, 8, "identity"),  # fewer threads (out*in) than positions per range

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times BASELINE configs[2] (HalfKA, 16 king buckets -> 1024x2 pairwise -> 16 -> 32 -> 1, 8 output buckets) at batch
-16384 on the generic (table-not-in-LDS) path: a parity-test configuration, reported for information only."""
+16384 (argv: H, segment): a parity-test configuration, reported for information only."""
 import os
 import sys
 import time
@@ -14,13 +14,14 @@ import bench  # noqa: E402
 from bullet_amd import lib  # noqa: E402
 
 H = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+SEG = int(sys.argv[2]) if len(sys.argv) > 2 else 768  # 0 = without the segment promise (any-shape FT kernels)
 B = 16384
 layout = [i // 4 for i in range(64)]  # 16 distinct king buckets
 idesc = lib.make_input_desc("chess_buckets", False, layout)
 rec = bench.synth_records(B, 0xB011E7003, "full")
 stm, ntm, bk, tg, w = lib.map_batch(idesc, rec, out_buckets=8, blend=0.75, threads=8)
 desc = lib.make_net_desc(num_inputs=768 * 16, nnz=32, ft_out=H, ft_act="crelu", pairwise=True, num_buckets=8,
-                         dense=[(16, "screlu", True), (32, "screlu", True), (1, "identity", True)])
+                         dense=[(16, "screlu", True), (32, "screlu", True), (1, "identity", True)], ft_segment=SEG)
 net = lib.Net(desc, B)
 net.init_weights()
 tb = net.make_batch(*[torch.from_numpy(a).cuda() for a in (stm, ntm, bk, tg, w)])
@@ -38,5 +39,5 @@ for _ in range(K):
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
 prof = lib.profile_stop()
-print(f"cfg3 H={H}: {B * K / el / 1e6:.2f} M pos/s, {el / K * 1e3:.3f} ms/step, loss {net.loss.item() / B:.6f}")
+print(f"cfg3 H={H} segment={SEG}: {B * K / el / 1e6:.2f} M pos/s, {el / K * 1e3:.3f} ms/step, loss {net.loss.item() / B:.6f}")
 print({k: round(1e3 * ms / K, 1) for k, (c, ms) in prof.items()})
