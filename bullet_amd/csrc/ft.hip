@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256) void ft_group_scan(int *__restrict__ blk_cnt, 
                                                      int *__restrict__ counts) {
     extern __shared__ __align__(16) int gl[];  // [nblk][nseg] counts -> exclusive prefixes
     __shared__ int tot[256], seg_start[257], ch_start[257], fi_start[257], bi_start[257];
+    __shared__ int fi_per[256], bi_per[256];  // a segment's items are equal shares (in passes of 128 entries / chunks)
     for (int i = threadIdx.x; i < nblk * nseg; i += blockDim.x) gl[i] = blk_cnt[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -201,7 +202,11 @@ __global__ __launch_bounds__(256) void ft_group_scan(int *__restrict__ blk_cnt, 
         for (int sg = 0; sg < nseg; sg++) {
             seg_start[sg] = a, ch_start[sg] = c, fi_start[sg] = f, bi_start[sg] = bi;
             const int n = tot[sg], nc = (n + FT_CHUNK - 1) / FT_CHUNK;
-            a += n, c += nc, f += (n + fwd_item - 1) / fwd_item, bi += (nc + g_ch - 1) / g_ch;
+            const int nf = (n + fwd_item - 1) / fwd_item, nb = (nc + g_ch - 1) / g_ch;
+            // equal shares instead of full items + a remainder: (n / nf) rounded up to whole passes; nf never grows
+            fi_per[sg] = nf ? ((n + nf - 1) / nf + 127) / 128 * 128 : fwd_item;
+            bi_per[sg] = nb ? (nc + nb - 1) / nb : g_ch;
+            a += n, c += nc, f += nf ? (n + fi_per[sg] - 1) / fi_per[sg] : 0, bi += nb ? (nc + bi_per[sg] - 1) / bi_per[sg] : 0;
         }
         seg_start[nseg] = a, ch_start[nseg] = c, fi_start[nseg] = f, bi_start[nseg] = bi;
         counts[0] = f, counts[1] = bi, counts[2] = c, counts[3] = 0;
@@ -220,12 +225,12 @@ __global__ __launch_bounds__(256) void ft_group_scan(int *__restrict__ blk_cnt, 
     }
     for (int i = threadIdx.x; i < fi_start[nseg]; i += blockDim.x) {
         const int sg = seg_of_slot(fi_start, i), j = i - fi_start[sg];
-        fitems[i] = make_int4(sg, seg_start[sg] + j * fwd_item, min(fwd_item, tot[sg] - j * fwd_item), 0);
+        fitems[i] = make_int4(sg, seg_start[sg] + j * fi_per[sg], min(fi_per[sg], tot[sg] - j * fi_per[sg]), 0);
     }
     for (int i = threadIdx.x; i < bi_start[nseg]; i += blockDim.x) {
         const int sg = seg_of_slot(bi_start, i), j = i - bi_start[sg];
         const int nc = ch_start[sg + 1] - ch_start[sg];
-        bitems[i] = make_int4(sg, ch_start[sg] + j * g_ch, min(g_ch, nc - j * g_ch), 0);
+        bitems[i] = make_int4(sg, ch_start[sg] + j * bi_per[sg], min(bi_per[sg], nc - j * bi_per[sg]), 0);
     }
 }
 
@@ -1137,12 +1142,21 @@ __device__ __forceinline__ void ft_bwd_lds_body(const float *__restrict__ grad_o
         *reinterpret_cast<float4 *>(pw + (size_t)f * d.stride + d.offset + tile_row(PAIR, rt, half_rows, t8 * 4)) =
             *reinterpret_cast<const float4 *>(acc + f * LDS_RT + t8 * 4);
     }
-    // bias partial: fixed-order sum over the 128 staging thread groups
+    // bias partial: fixed-order sum over the 128 staging thread groups, in two levels (8 x 16) so the chain of
+    // dependent LDS reads is 16 + 8 long instead of 128
     *reinterpret_cast<float4 *>(gt + el0 * LDS_RT + s8 * 4) = bsum;
+    __syncthreads();
+    float bpart = 0.0f;
+    if (threadIdx.x < 8 * LDS_RT) {
+        const int col = threadIdx.x & (LDS_RT - 1), part = threadIdx.x / LDS_RT;
+        for (int i = 0; i < 16; i++) bpart += gt[(part * 16 + i) * LDS_RT + col];
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 * LDS_RT) gt[threadIdx.x] = bpart;
     __syncthreads();
     if (threadIdx.x < LDS_RT) {
         float s = 0.0f;
-        for (int i = 0; i < 128; i++) s += gt[i * LDS_RT + threadIdx.x];
+        for (int i = 0; i < 8; i++) s += gt[i * LDS_RT + threadIdx.x];
         partial_b[(size_t)cg * d.rows + tile_row(PAIR, rt, half_rows, threadIdx.x)] = s;
     }
 }
@@ -1318,9 +1332,9 @@ int ft_plan(const bt_ft_desc *d, FtPlan *p) {
     p->ntiles = d->rows / LDS_RT;
     p->G = 1, p->chunks_per_wg = p->nchunks;
     if (p->grouped) {
-        // item sizes: ~1024 / ntiles forward items and ~768 / ntiles backward items per launch, so the grid has a
-        // few workgroups per CU and no item is more than a fraction of a CU's share
-        const int tgt_f = std::max(1, 1024 / p->ntiles), tgt_b = std::max(1, 768 / p->ntiles);
+        // item sizes: ~512 / ntiles items per launch (two workgroups per CU when the segments are balanced; every
+        // workgroup pays a few us of tile load / slab write-back, so smaller items cost more than they balance)
+        const int tgt_f = std::max(1, 512 / p->ntiles), tgt_b = std::max(1, 512 / p->ntiles);
         int fi = (int)std::min<long long>(4096, std::max<long long>(128, (E / tgt_f + 127) / 128 * 128));
         int gc = std::max(1, std::min(16, p->max_chunks / tgt_b));
         p->fwd_item = env_int("BT_FT_FWD_ITEM", fi), p->g_ch = env_int("BT_FT_BWD_CHUNKS", gc);
