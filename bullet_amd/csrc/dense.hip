@@ -683,6 +683,48 @@ constexpr int DM_CHUNK = 64;    // positions per workgroup, forward / dX
 constexpr int DM_RANGE = 128;   // positions per workgroup, dW
 constexpr int DM_OH = 8;        // output rows per workgroup, dW
 
+// Positions sorted by output bucket (stable) for the kernels below: with real data every chunk of consecutive
+// positions holds all the buckets, and a chunk re-stages the bucket's 64 KiB of weights once per bucket present;
+// walking the batch in bucket order makes that once per chunk. net.hip builds the permutation once per step
+// (bucket_perm_kernel) and installs it for the calling thread; the public bt_dense_* entry points run without.
+thread_local const int32_t *g_dense_perm = nullptr;
+constexpr int BP_THREADS = 1024;
+
+__global__ __launch_bounds__(BP_THREADS) void bucket_perm_kernel(const int32_t *__restrict__ bucket, int batch, int nb,
+                                                                 int32_t *__restrict__ perm) {
+    extern __shared__ __align__(16) int bp_cnt[];  // [nb][BP_THREADS]: counts, then write cursors; then [batch] bytes
+    __shared__ int wsum[BP_THREADS / 64];
+    uint8_t *s_b = reinterpret_cast<uint8_t *>(bp_cnt + nb * BP_THREADS);  // the buckets, read once (coalesced)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per = (batch + BP_THREADS - 1) / BP_THREADS;
+    const int p_lo = min(batch, t * per), p_hi = min(batch, p_lo + per);
+    for (int p = t; p < batch; p += BP_THREADS) s_b[p] = (uint8_t)min(max(bucket[p], 0), nb - 1);
+    for (int k = 0; k < nb; k++) bp_cnt[k * BP_THREADS + t] = 0;
+    __syncthreads();
+    for (int p = p_lo; p < p_hi; p++) bp_cnt[s_b[p] * BP_THREADS + t]++;
+    __syncthreads();
+    // exclusive scan of the flattened (bucket major, thread minor) counts; thread t scans elements [t*nb, (t+1)*nb)
+    int s = 0;
+    for (int k = 0; k < nb; k++) s += bp_cnt[t * nb + k];
+    int incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int run = incl - s;
+    for (int w2 = 0; w2 < wave; w2++) run += wsum[w2];
+    for (int k = 0; k < nb; k++) {
+        const int v = bp_cnt[t * nb + k];
+        bp_cnt[t * nb + k] = run;
+        run += v;
+    }
+    __syncthreads();
+    for (int p = p_lo; p < p_hi; p++) perm[bp_cnt[s_b[p] * BP_THREADS + t]++] = p;
+}
+
 bool dense_mid_ok(const bt_dense_desc *d) {
     return d->out > 1 && d->out <= 32 && d->buckets <= 32 && d->in % 256 == 0 && d->in / 256 <= 8 &&
            (size_t)d->out * (d->in + 4) * sizeof(float) <= 144 * 1024;
@@ -721,10 +763,11 @@ template <int NX, bool DX>
 __global__ __launch_bounds__(DM_THREADS) void dense_mid_kernel(const float *__restrict__ w, const float *__restrict__ bias,
                                                                const float *__restrict__ src,
                                                                const int32_t *__restrict__ bucket,
-                                                               float *__restrict__ dst, bt_dense_desc d) {
+                                                               float *__restrict__ dst, bt_dense_desc d,
+                                                               const int32_t *__restrict__ perm) {
     extern __shared__ __align__(16) float wt[];  // [out][in + 4]: the current bucket's rows, transposed (16-B aligned)
     __shared__ uint8_t s_bk[DM_RANGE];
-    __shared__ int s_list[DM_RANGE], s_wcnt[DM_RANGE / 64];
+    __shared__ int s_list[DM_RANGE], s_wcnt[DM_RANGE / 64], s_pos[DM_RANGE];
     __shared__ unsigned s_mask;
     const int rows = d.out * d.buckets, ldw = d.in + 4;
     const int b0 = blockIdx.x * DM_CHUNK, npos = min(DM_CHUNK, d.batch - b0);
@@ -732,7 +775,9 @@ __global__ __launch_bounds__(DM_THREADS) void dense_mid_kernel(const float *__re
     if (threadIdx.x == 0) s_mask = 0;
     __syncthreads();
     if ((int)threadIdx.x < npos) {
-        const int bk = (d.buckets > 1) ? bucket[b0 + threadIdx.x] : 0;
+        const int pos = perm ? perm[b0 + threadIdx.x] : b0 + (int)threadIdx.x;
+        const int bk = (d.buckets > 1) ? bucket[pos] : 0;
+        s_pos[threadIdx.x] = pos;
         s_bk[threadIdx.x] = (uint8_t)bk;
         atomicOr(&s_mask, 1u << bk);
     }
@@ -750,7 +795,7 @@ __global__ __launch_bounds__(DM_THREADS) void dense_mid_kernel(const float *__re
         // the output loop has no dependent global load
         const float bias_l = (!DX && lane < d.out) ? bias[bk * d.out + lane] : 0.0f;
         for (int j = wave; j < cnt; j += DM_THREADS / 64) {
-            const int b = b0 + __builtin_amdgcn_readfirstlane(s_list[j]);
+            const int b = __builtin_amdgcn_readfirstlane(s_pos[s_list[j]]);
             if constexpr (!DX) {
                 const float4 *xb = reinterpret_cast<const float4 *>(src + (size_t)b * d.in);
                 float4 xv[NX];
@@ -796,15 +841,20 @@ __global__ __launch_bounds__(DM_THREADS) void dense_mid_kernel(const float *__re
 __global__ __launch_bounds__(DM_THREADS) void dense_mid_dw_kernel(const float *__restrict__ x,
                                                                   const int32_t *__restrict__ bucket,
                                                                   const float *__restrict__ gz, float *__restrict__ part_w,
-                                                                  float *__restrict__ part_b, bt_dense_desc d) {
+                                                                  float *__restrict__ part_b, bt_dense_desc d,
+                                                                  const int32_t *__restrict__ perm) {
     __shared__ uint8_t s_bk[DM_RANGE];
-    __shared__ int s_list[DM_RANGE], s_wcnt[DM_RANGE / 64];
+    __shared__ int s_list[DM_RANGE], s_wcnt[DM_RANGE / 64], s_pos[DM_RANGE];
     const int rows = d.out * d.buckets;
     const int b0 = blockIdx.x * DM_RANGE, npos = min(DM_RANGE, d.batch - b0);
     const int o0 = blockIdx.y * DM_OH, noh = min(DM_OH, d.out - o0);
     const int i0 = threadIdx.x, i1 = threadIdx.x + DM_THREADS;
     const bool c0 = i0 < d.in, c1 = i1 < d.in;
-    if ((int)threadIdx.x < npos) s_bk[threadIdx.x] = (uint8_t)((d.buckets > 1) ? bucket[b0 + threadIdx.x] : 0);
+    if ((int)threadIdx.x < npos) {
+        const int pos = perm ? perm[b0 + threadIdx.x] : b0 + (int)threadIdx.x;
+        s_pos[threadIdx.x] = pos;
+        s_bk[threadIdx.x] = (uint8_t)((d.buckets > 1) ? bucket[pos] : 0);
+    }
     __syncthreads();
     float *pw = part_w + (size_t)blockIdx.x * rows * d.in;
     for (int bk = 0; bk < d.buckets; bk++) {
@@ -818,7 +868,7 @@ __global__ __launch_bounds__(DM_THREADS) void dense_mid_dw_kernel(const float *_
         auto load = [&](int j0, float(&x0)[U], float(&x1)[U], float(&gl)[U]) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int b = b0 + __builtin_amdgcn_readfirstlane(s_list[min(j0 + u, max(cnt - 1, 0))]);
+                const int b = __builtin_amdgcn_readfirstlane(s_pos[s_list[min(j0 + u, max(cnt - 1, 0))]]);
                 x0[u] = c0 ? x[(size_t)b * d.in + i0] : 0.0f;
                 x1[u] = c1 ? x[(size_t)b * d.in + i1] : 0.0f;
                 const int lo = threadIdx.x & 63;
@@ -1045,14 +1095,17 @@ int dense_mid_launch(hipStream_t s, const bt_dense_desc *d, const float *w, cons
                      const int32_t *bucket, float *dst, bool dx) {
     const size_t lds = (size_t)d->out * (d->in + 4) * sizeof(float);
     dim3 grid(bt_div_up(d->batch, DM_CHUNK)), block(DM_THREADS);
+    const int32_t *perm = d->buckets > 1 ? g_dense_perm : nullptr;
 #define DML(NX)                                                                                                      \
     case NX:                                                                                                         \
         if (dx) {                                                                                                    \
             if (int rc = dense_set_lds(dense_mid_kernel<NX, true>, lds)) return rc;                                  \
-            BT_LAUNCH(BTK_DENSE_BWD_DX, s, (dense_mid_kernel<NX, true>), grid, block, lds, w, bias, src, bucket, dst, *d); \
+            BT_LAUNCH(BTK_DENSE_BWD_DX, s, (dense_mid_kernel<NX, true>), grid, block, lds, w, bias, src, bucket, dst, *d, \
+                      perm);                                                                                         \
         } else {                                                                                                     \
             if (int rc = dense_set_lds(dense_mid_kernel<NX, false>, lds)) return rc;                                 \
-            BT_LAUNCH(BTK_DENSE_FWD, s, (dense_mid_kernel<NX, false>), grid, block, lds, w, bias, src, bucket, dst, *d);  \
+            BT_LAUNCH(BTK_DENSE_FWD, s, (dense_mid_kernel<NX, false>), grid, block, lds, w, bias, src, bucket, dst, *d,   \
+                      perm);                                                                                         \
         }                                                                                                            \
         break;
     switch (d->in / 256) {
@@ -1075,6 +1128,21 @@ int dense_validate(const bt_dense_desc *d, const char *who) {
 }  // namespace
 
 // ---- internal entry points used by net.hip (declared in common.h)
+// bucket-sorted position order for the mid-size bucketed layers (see g_dense_perm)
+bool bt_internal_dense_wants_perm(const bt_dense_desc *d) {
+    return dense_validate(d, "dense_wants_perm") == BT_OK && d->buckets > 1 && d->buckets <= 16 && !dense_fwd_small_ok(d) &&
+           dense_mid_ok(d);
+}
+int bt_internal_bucket_perm(void *stream, const int32_t *bucket, int batch, int nb, int32_t *perm) {
+    BT_REQUIRE(bucket && perm && batch > 0 && batch <= 64 * 1024 && nb > 1 && nb <= 16, "bucket_perm: bad arguments");
+    const size_t lds = (size_t)nb * BP_THREADS * sizeof(int) + bt_align((size_t)batch, 16);
+    if (int rc = dense_set_lds(bucket_perm_kernel, lds)) return rc;
+    BT_LAUNCH(BTK_DENSE_FWD, bt_stream(stream), bucket_perm_kernel, dim3(1), dim3(BP_THREADS), lds, bucket, batch, nb, perm);
+    BT_LAUNCH_CHECK();
+    return BT_OK;
+}
+void bt_internal_dense_set_perm(const int32_t *perm) { g_dense_perm = perm; }
+
 bool bt_internal_dense_head_ok(const bt_dense_desc *d) { return dense_validate(d, "dense_head_ok") == BT_OK && dense_bwd_small_ok(d); }
 
 int bt_internal_dense_backward_head(void *stream, const bt_dense_desc *d, const float *w, const float *x,
@@ -1203,7 +1271,7 @@ int bt_dense_backward(void *stream, const bt_dense_desc *d, const float *w, cons
             if (grad_x)
                 if (int rc = dense_mid_launch(s, d, w, nullptr, gz, bucket, grad_x, true)) return rc;
             BT_LAUNCH(BTK_DENSE_BWD_DW, s, dense_mid_dw_kernel, dim3(nrm, bt_div_up(d->out, DM_OH)), dim3(DM_THREADS), 0, x,
-                      bucket, gz, pw, pb, *d);
+                      bucket, gz, pw, pb, *d, d->buckets > 1 ? g_dense_perm : nullptr);
             BT_LAUNCH_CHECK();
         }
         BT_LAUNCH(BTK_SUM_PARTIALS, s, sum_partials_t_kernel, dim3(bt_div_up((long long)rows * d->in, 256)), dim3(256), 0, pw,

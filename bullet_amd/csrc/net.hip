@@ -37,10 +37,11 @@ struct bt_net {
     // gzp[k] the gradient w.r.t. z; yfin = last layer + skip neurons; weff = l0w + l0f.repeat(NB)
     float *ap[BT_MAX_DENSE] = {nullptr}, *gzp[BT_MAX_DENSE] = {nullptr};
     float *yfin = nullptr, *weff = nullptr;
+    int32_t *perm = nullptr;  // [B] positions in output-bucket order for the mid-size bucketed layers (dense.hip)
     void *ft_ws = nullptr, *dense_ws = nullptr;
     // side stream: the FT sorted index (depends only on the batch indices) is built while the forward runs
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_index = nullptr, ev_fwd = nullptr, ev_head = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_index = nullptr, ev_fwd = nullptr, ev_head = nullptr, ev_perm = nullptr;
     size_t ft_ws_bytes = 0, dense_ws_bytes = 0;
 };
 
@@ -202,10 +203,24 @@ int check_batch(const bt_net *net, const bt_batch *b, const char *who) {
     return BT_OK;
 }
 
+// builds the bucket-order permutation of this batch (if the net has a layer that uses one) and installs it for the
+// calling thread until the scope ends
+struct PermScope {
+    int rc = BT_OK;
+    bool built = false;
+    PermScope(bt_net *n, hipStream_t s, const bt_batch *b) {
+        if (!n->perm || !b->buckets || b->batch > 64 * 1024) return;
+        rc = bt_internal_bucket_perm(s, b->buckets, b->batch, n->d.num_buckets, n->perm);
+        if (rc == BT_OK) bt_internal_dense_set_perm(n->perm), built = true;
+    }
+    ~PermScope() { bt_internal_dense_set_perm(nullptr); }
+};
+
 // groups_ready: the segment entry lists of this batch are already in ft_ws (bt_net_forward_backward builds them
 // before it forks the side stream); otherwise they are built here, in stream order
+// perm_on_side: the bucket-order permutation is being built on the side stream (ev_perm): joined before the layers
 int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bool want_gz0 = false,
-                 bool head_in_ft = false, bool groups_ready = false) {
+                 bool head_in_ft = false, bool groups_ready = false, bool perm_on_side = false) {
     bt_ft_desc f = ft_desc(n, b->batch);
     const int32_t *idx[2] = {b->stm, b->nstm};
     const float *w0 = nullptr;
@@ -234,6 +249,7 @@ int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bo
                                         n->ft_ws_bytes))
         return rc;
     const float *x = n->hid;
+    if (perm_on_side) BT_HIP(hipStreamWaitEvent(s, n->ev_perm, 0));
     for (int k = 0; k < n->d.n_dense; k++) {
         bt_dense_desc q = dn_desc(n, k, b->batch);
         if (fuse_loss && k == n->d.n_dense - 1) {
@@ -363,6 +379,11 @@ int bt_net_create(const bt_net_desc *desc, int max_batch, float *ext_params, flo
         if (wsb == 0) return fail(BT_ERR_INVALID);
         if (wsb > n->dense_ws_bytes) n->dense_ws_bytes = wsb;
     }
+    for (int k = 0; k < desc->n_dense && !n->perm; k++) {
+        bt_dense_desc q = dn_desc(n, k, max_batch);
+        if (bt_internal_dense_wants_perm(&q))
+            if ((rc = bt_malloc(reinterpret_cast<void **>(&n->perm), B * sizeof(int32_t)))) return fail(rc);
+    }
     bt_ft_desc f = ft_desc(n, max_batch);
     n->ft_ws_bytes = bt_ft_backward_workspace_bytes(&f);
     if (n->ft_ws_bytes == 0) return fail(BT_ERR_INVALID);
@@ -372,7 +393,8 @@ int bt_net_create(const bt_net_desc *desc, int max_batch, float *ext_params, flo
         hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&n->ev_index, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&n->ev_fwd, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&n->ev_head, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&n->ev_head, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&n->ev_perm, hipEventDisableTiming) != hipSuccess) {
         bt_set_error("bt_net_create: could not create the side stream / events");
         return fail(BT_ERR_HIP);
     }
@@ -387,12 +409,13 @@ int bt_net_destroy(bt_net *n) {
     bt_free(n->mom), bt_free(n->vel), bt_free(n->hid), bt_free(n->g_hid), bt_free(n->saved), bt_free(n->grad_y);
     bt_free(n->gz0), bt_free(n->loss_partials), bt_free(n->zpart);
     for (int k = 0; k < BT_MAX_DENSE; k++) bt_free(n->a[k]), bt_free(n->ga[k]), bt_free(n->ap[k]), bt_free(n->gzp[k]);
-    bt_free(n->yfin), bt_free(n->weff), bt_free(n->slow);
+    bt_free(n->yfin), bt_free(n->weff), bt_free(n->slow), bt_free(n->perm);
     bt_free(n->ft_ws), bt_free(n->dense_ws);
     if (n->ev_fork) (void)hipEventDestroy(n->ev_fork);
     if (n->ev_index) (void)hipEventDestroy(n->ev_index);
     if (n->ev_fwd) (void)hipEventDestroy(n->ev_fwd);
     if (n->ev_head) (void)hipEventDestroy(n->ev_head);
+    if (n->ev_perm) (void)hipEventDestroy(n->ev_perm);
     if (n->side) (void)hipStreamDestroy(n->side);
     delete n;
     return BT_OK;
@@ -414,6 +437,8 @@ int bt_net_set_adamw(bt_net *n, int t, float decay, float beta1, float beta2, fl
 int bt_net_forward(bt_net *n, void *stream, const bt_batch *b, float *out_dev, float *loss_sum_dev) {
     if (int rc = check_batch(n, b, "bt_net_forward")) return rc;
     hipStream_t s = bt_stream(stream);
+    PermScope perm(n, s, b);
+    if (perm.rc) return perm.rc;
     if (int rc = forward_impl(n, s, b, false)) return rc;
     const float *y = net_output(n);
     const int n_out = n->d.dense_out[n->d.n_dense - 1];
@@ -435,6 +460,9 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
     // fork: sorted index build on the side stream, ordered after everything already queued on `s`
     BT_HIP(hipEventRecord(n->ev_fork, s));
     BT_HIP(hipStreamWaitEvent(n->side, n->ev_fork, 0));
+    PermScope perm(n, n->side, b);  // (multi-layer bucketed nets) needed after the FT forward: side stream first
+    if (perm.rc) return perm.rc;
+    if (perm.built) BT_HIP(hipEventRecord(n->ev_perm, n->side));
     if (int rc = bt_internal_ft_build_sorted(n->side, &f, idx, n->ft_ws, n->ft_ws_bytes)) return rc;
     BT_HIP(hipEventRecord(n->ev_index, n->side));
     const int L = n->d.n_dense;
@@ -449,7 +477,7 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
     // HBM-bound in a small-footprint kernel shape, the other LDS-bound, and they share the CUs.
     const bool side_head = fuse_loss && fuse_ft && L == 1;
     const bool head_in_ft = side_head && bt_internal_ft_forward_head_ok(&f, q0.buckets) && b->batch <= 1024 * 64;
-    if (int rc = forward_impl(n, s, b, fuse_loss, side_head, head_in_ft, true)) return rc;
+    if (int rc = forward_impl(n, s, b, fuse_loss, side_head, head_in_ft, true, perm.built)) return rc;
     if (!fuse_loss)
         if (int rc = bt_loss(s, n->d.loss_kind, b->batch, n->d.dense_out[L - 1], net_output(n), b->targets,
                              n->d.use_entry_weights ? b->entry_weights : nullptr, n->d.loss_power, loss_sum_dev,

@@ -18,7 +18,11 @@ SEG = int(sys.argv[2]) if len(sys.argv) > 2 else 768  # 0 = without the segment 
 B = 16384
 layout = [i // 4 for i in range(64)]  # 16 distinct king buckets
 idesc = lib.make_input_desc("chess_buckets", False, layout)
-rec = bench.synth_records(B, 0xB011E7003, "full")
+if len(sys.argv) > 3:  # real positions (bulletformat file) instead of the synthetic generator: skewed king buckets
+    allrec = np.fromfile(sys.argv[3], dtype=np.uint8).reshape(-1, 32)
+    rec = allrec[np.arange(B) % allrec.shape[0]].reshape(-1).copy()
+else:
+    rec = bench.synth_records(B, 0xB011E7003, "full")
 stm, ntm, bk, tg, w = lib.map_batch(idesc, rec, out_buckets=8, blend=0.75, threads=8)
 desc = lib.make_net_desc(num_inputs=768 * 16, nnz=32, ft_out=H, ft_act="crelu", pairwise=True, num_buckets=8,
                          dense=[(16, "screlu", True), (32, "screlu", True), (1, "identity", True)], ft_segment=SEG)
