@@ -258,6 +258,45 @@ def test_full_size_config2_properties():
     net.close()
 
 
+def test_full_size_config3_properties():
+    """BASELINE configs[2] at its full size (HalfKA, 16 king buckets, F = 12288 -> 1024x2 pairwise -> 16 -> 32 -> 1,
+    8 output buckets, B = 16384, real positions): size-independent checks of the segment-grouped path.
+    (a) bit-identical gradients run to run; (b) same loss bits and the same gradients (summation-order bar) as the
+    any-shape kernels without the segment promise; (c) king-column sums of dW0 == 2 x bias gradient; (d) loss vs oracle."""
+    layout = [i // 4 for i in range(64)]
+    cfg = dict(num_inputs=768 * 16, nnz=32, ft_out=1024, ft_act="crelu", pairwise=True, num_buckets=8,
+               dense=[(16, "screlu", True), (32, "screlu", True), (1, "identity", True)])
+    (stm, ntm, bk, tg, w), = fixture_batches("chess_buckets", layout, False, 8, 0.75, 1)
+    do = ob.make_net(**cfg)
+    params = ob.net_init(do, ft_eff=32)
+    params[1][:] = 0.3  # a bias that keeps a good share of the CReLU'd rows strictly inside (0, 1)
+    batch = [gu.dev(a) for a in (stm, ntm, bk, tg, w)]
+    res = {}
+    for seg in (768, 0):
+        net = lib.Net(lib.make_net_desc(**cfg, ft_segment=seg), 16384)
+        net.set_params(params)
+        tb = net.make_batch(*batch)
+        net.forward_backward(tb)
+        torch.cuda.synchronize()
+        g1, l1 = net.grads.clone(), net.loss.item()
+        net.forward_backward(tb)
+        torch.cuda.synchronize()
+        assert torch.equal(g1, net.grads) and l1 == net.loss.item()  # (a)
+        res[seg] = (l1, [net.tensor(g1, t).clone() for t in range(net.n_tensors)])
+        net.close()
+    (l_seg, g_seg), (l_any, g_any) = res[768], res[0]
+    assert l_seg == l_any  # (b) the forward pass keeps every summation order
+    for t, (a, b) in enumerate(zip(g_seg, g_any)):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-5 * float(b.abs().max()), msg=lambda m: f"tensor {t}: {m}")
+    gw, gb = g_seg[0].view(16, 768, 1024).double(), g_seg[1].double()
+    kings = gw[:, 320:384].sum((0, 1)) + gw[:, 384 + 320:768].sum((0, 1))  # own + opponent king columns, all buckets
+    torch.testing.assert_close(kings, 2 * gb, rtol=2e-4, atol=1e-4 * float(gb.abs().max()))  # (c)
+    assert float(gb.abs().max()) > 0
+    loss_ref = ob.lib().orc_net_forward(C.byref(do), 16384, ob.ptr_array(params), ob.ip(stm), ob.ip(ntm), ob.ip(bk),
+                                        ob.fp(tg), ob.fp(w), None)
+    assert abs(l_seg - loss_ref) <= 1e-5 * abs(loss_ref)  # (d)
+
+
 @pytest.mark.parametrize("hidden,expected", [(32, "0.056420"), (128, "0.044886")])
 def test_train_run_reproduces_reference_examples(hidden, expected):
     """examples/tests/test1.rs / test3.rs end to end through bt_train_run: reader (looping batch.bf), threaded
@@ -303,6 +342,29 @@ def test_train_run_wdl_output_matches_manual_steps():
     assert per_batch == manual and torch.equal(w_run, net.params)
     assert 0.9 < manual[0] < 1.3  # ~ln 3 at initialisation
     net.close()
+
+
+def test_train_run_king_bucketed_net_with_segment_promise():
+    """bt_train_run on a king-bucketed net (ChessBucketsMirrored, 4 buckets): the segment-grouped kernels give the
+    same training run as the any-shape ones (forward bit-identical; weight gradients differ in summation order only)"""
+    layout = [0, 0, 1, 1] * 2 + [2] * 8 + [3] * 16
+    idesc = lib.make_input_desc("chess_buckets_mirrored", False, layout)
+    lr, wdl = lib.LrSched(lib.LR["constant"], 0.001, 0, 0, 0), lib.WdlSched(lib.WDL["constant"], 0.4, 0, 0)
+    runs = {}
+    for seg in (768, 0):
+        cfg = dict(num_inputs=768 * 4, nnz=32, ft_out=128, ft_act="screlu", num_buckets=8,
+                   dense=[(1, "identity", True)], ft_segment=seg)
+        net = lib.Net(lib.make_net_desc(**cfg), 4096)
+        net.init_weights(seed=11)
+        losses = []
+        net.train(idesc, [GOLDEN], 4096, 4, 2, lr, wdl, out_buckets=8, threads=2,
+                  on_batch=lambda sb, b, l: losses.append(l))
+        runs[seg] = (losses, net.params.clone())
+        net.close()
+    (la, wa), (lb, wb) = runs[768], runs[0]
+    assert len(la) == 8 and la[0] == lb[0] and not any(np.isnan(la))
+    np.testing.assert_allclose(la, lb, rtol=2e-5)
+    torch.testing.assert_close(wa, wb, rtol=1e-4, atol=2e-5)
 
 
 def test_train_run_resume_matches_continuous_run(tmp_path):
