@@ -127,6 +127,8 @@ def main():
                     help="also time bt_train_run (file reader + threaded mapper + pinned H2D + step) over this many "
                          "batches and report it as `live_loader` (not part of `value`)")
     ap.add_argument("--loader-threads", type=int, default=16)
+    ap.add_argument("--host-mapper", action="store_true",
+                    help="--live-loader with the threaded host mapper instead of the device mapper")
     args = ap.parse_args()
 
     import torch
@@ -251,8 +253,10 @@ def main():
                 synth_records(B * 8, 0xB011E7000 + 99, args.occupancy).tofile(path)
                 nb = args.live_loader
                 rep = net.train(idesc, [path], B, nb, 2, lib.LrSched(lib.LR["constant"], 1e-3, 0, 0, 0),
-                                lib.WdlSched(lib.WDL["constant"], 0.75, 0, 0), out_buckets=8, threads=args.loader_threads)
+                                lib.WdlSched(lib.WDL["constant"], 0.75, 0, 0), out_buckets=8, threads=args.loader_threads,
+                                device_mapper=not args.host_mapper)
                 out["live_loader"] = {"positions_per_sec": rep[-1][2], "batches": nb, "threads": args.loader_threads,
+                                      "mapper": "host" if args.host_mapper else "device",
                                       "note": "second superbatch of bt_train_run: reader + mapper + H2D + step"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(batches[0], B)

@@ -259,12 +259,15 @@ namespace {
 struct HostSlot {  // one prepared batch in pinned memory (PreparedBatchHost)
     int32_t *stm = nullptr, *nstm = nullptr, *buckets = nullptr;
     float *targets = nullptr, *weights = nullptr;
+    uint8_t *records = nullptr;  // device_mapper: the raw records instead of the mapped tensors
+    float blend = 0.0f;
     int superbatch = 0, batch = 0;
 };
 
 struct DevSet {
     int32_t *stm = nullptr, *nstm = nullptr, *buckets = nullptr;
     float *targets = nullptr, *weights = nullptr;
+    uint8_t *records = nullptr;
 };
 
 struct Loader {
@@ -319,9 +322,10 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
         (void)hipDeviceSynchronize();
         for (auto &s : slots) {
             bt_host_free_pinned(s.stm), bt_host_free_pinned(s.nstm), bt_host_free_pinned(s.buckets);
-            bt_host_free_pinned(s.targets), bt_host_free_pinned(s.weights);
+            bt_host_free_pinned(s.targets), bt_host_free_pinned(s.weights), bt_host_free_pinned(s.records);
         }
-        for (auto &d : dev) bt_free(d.stm), bt_free(d.nstm), bt_free(d.buckets), bt_free(d.targets), bt_free(d.weights);
+        for (auto &d : dev)
+            bt_free(d.stm), bt_free(d.nstm), bt_free(d.buckets), bt_free(d.targets), bt_free(d.weights), bt_free(d.records);
         for (auto e : uploaded) if (e) (void)hipEventDestroy(e);
         for (auto e : consumed) if (e) (void)hipEventDestroy(e);
         for (auto e : slot_copied) if (e) (void)hipEventDestroy(e);
@@ -348,7 +352,12 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
         }                                                                            \
     } while (0)
 
+    const bool dev_map = cfg->device_mapper != 0;
     for (auto &s : slots) {
+        if (dev_map) {
+            TRY(pinned((void **)&s.records, (size_t)B * 32));
+            continue;
+        }
         TRY(pinned((void **)&s.stm, sizeof(int32_t) * (size_t)B * nnz));
         TRY(pinned((void **)&s.nstm, sizeof(int32_t) * (size_t)B * nnz));
         TRY(pinned((void **)&s.buckets, sizeof(int32_t) * (size_t)B));
@@ -363,6 +372,11 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
         TRY(bt_malloc((void **)&d.buckets, sizeof(int32_t) * (size_t)B));
         TRY(bt_malloc((void **)&d.targets, sizeof(float) * (size_t)B * tw));
         TRY(bt_malloc((void **)&d.weights, sizeof(float) * (size_t)B));
+        if (dev_map) {
+            TRY(bt_malloc((void **)&d.records, (size_t)B * 32));
+            TRY_HIP(hipMemset(d.stm, 0, sizeof(int32_t) * (size_t)B * nnz));  // (slots behind a terminator are never written)
+            TRY_HIP(hipMemset(d.nstm, 0, sizeof(int32_t) * (size_t)B * nnz));
+        }
     }
     TRY(bt_stream_create(&copy_stream));
     TRY(bt_stream_create(&compute_stream));
@@ -381,6 +395,16 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
         TRY(bt_stream_sync(compute_stream));
     }
 
+    auto map_opts = [&](float blend) {
+        bt_map_opts o;
+        o.out_buckets = cfg->out_buckets;
+        o.blend = blend;
+        o.eval_scale = cfg->eval_scale;
+        o.use_win_rate_model = cfg->use_win_rate_model;
+        o.wdl_output = cfg->wdl_output;
+        o.threads = cfg->threads;
+        return o;
+    };
     // ---- loader thread (run.rs:94-103): reader -> mapper -> queue of prepared batches
     for (int i = 0; i < RING; i++) L.free_slots.push_back(i);
     loader_thread = std::thread([&]() {
@@ -394,16 +418,20 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
                 slot = L.free_slots.front();
                 L.free_slots.pop_front();
             }
-            bt_map_opts o;
-            o.out_buckets = cfg->out_buckets;
-            o.blend = bt_wdl_at(&cfg->wdl, batch, sb, cfg->end_superbatch);
-            o.eval_scale = cfg->eval_scale;
-            o.use_win_rate_model = cfg->use_win_rate_model;
-            o.wdl_output = cfg->wdl_output;
-            o.threads = cfg->threads;
+            bt_map_opts o = map_opts(bt_wdl_at(&cfg->wdl, batch, sb, cfg->end_superbatch));
             HostSlot &s = slots[slot];
-            int lrc = bt_reader_next(reader, records.data(), B);
-            if (!lrc) lrc = bt_map_batch(input, &o, records.data(), B, s.stm, s.nstm, s.buckets, s.targets, s.weights);
+            s.blend = o.blend;
+            int lrc;
+            if (dev_map) {  // raw records straight into the pinned slot; the device maps them after the upload
+                lrc = bt_reader_next(reader, s.records, B);
+                if (!lrc && !o.wdl_output && !(o.blend >= 0.0f && o.blend <= 1.0f)) {
+                    bt_set_error("WDL proportion must be in [0, 1]");  // value.rs:114
+                    lrc = BT_ERR_INVALID;
+                }
+            } else {
+                lrc = bt_reader_next(reader, records.data(), B);
+                if (!lrc) lrc = bt_map_batch(input, &o, records.data(), B, s.stm, s.nstm, s.buckets, s.targets, s.weights);
+            }
             s.superbatch = sb, s.batch = batch;
             {
                 std::lock_guard<std::mutex> g(L.mu);
@@ -434,6 +462,16 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
     auto upload = [&](int slot, int set) -> int {  // PreparedBatchHost::copy_to_device_async, dataloader.rs:41-54
         HostSlot &s = slots[slot];
         DevSet &d = dev[set];
+        if (dev_map) {
+            if (int r2 = bt_memcpy_h2d_async(d.records, s.records, (size_t)B * 32, copy_stream)) return r2;
+            BT_HIP(hipEventRecord(slot_copied[slot], bt_stream(copy_stream)));
+            const bt_map_opts o = map_opts(s.blend);
+            if (int r2 = bt_map_batch_device(copy_stream, input, &o, d.records, B, d.stm, d.nstm, d.buckets, d.targets,
+                                             d.weights))
+                return r2;
+            BT_HIP(hipEventRecord(uploaded[set], bt_stream(copy_stream)));
+            return BT_OK;
+        }
         if (int r2 = bt_memcpy_h2d_async(d.stm, s.stm, sizeof(int32_t) * (size_t)B * nnz, copy_stream)) return r2;
         if (int r2 = bt_memcpy_h2d_async(d.nstm, s.nstm, sizeof(int32_t) * (size_t)B * nnz, copy_stream)) return r2;
         if (int r2 = bt_memcpy_h2d_async(d.buckets, s.buckets, sizeof(int32_t) * (size_t)B, copy_stream)) return r2;

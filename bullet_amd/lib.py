@@ -101,7 +101,7 @@ class TrainConfig(C.Structure):
     _fields_ = [("batch_size", C.c_int), ("batches_per_superbatch", C.c_int), ("start_superbatch", C.c_int),
                 ("end_superbatch", C.c_int), ("lr", LrSched), ("wdl", WdlSched), ("eval_scale", C.c_float),
                 ("out_buckets", C.c_int), ("use_win_rate_model", C.c_int), ("threads", C.c_int),
-                ("log_rate", C.c_int), ("wdl_output", C.c_int)]
+                ("log_rate", C.c_int), ("wdl_output", C.c_int), ("device_mapper", C.c_int)]
 
 
 BATCH_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_float)
@@ -130,7 +130,7 @@ SYMBOLS = [
     "bt_net_param_count", "bt_net_num_tensors", "bt_net_tensor_size", "bt_net_tensor_offset", "bt_net_create",
     "bt_net_destroy", "bt_net_params", "bt_net_grads", "bt_net_momentum", "bt_net_velocity", "bt_net_set_adamw",
     "bt_net_forward_backward", "bt_net_optimiser_step", "bt_net_forward",
-    "bt_input_init", "bt_input_num_inputs", "bt_input_max_active", "bt_map_batch",
+    "bt_input_init", "bt_input_num_inputs", "bt_input_max_active", "bt_map_batch", "bt_map_batch_device",
     "bt_net_init_weights_host", "bt_lr_at", "bt_wdl_at", "bt_reader_open", "bt_reader_next", "bt_reader_close",
     "bt_train_run",
     "bt_net_tensor_name", "bt_net_tensor_shape", "bt_checkpoint_write", "bt_checkpoint_read", "bt_save_quantised",
@@ -213,6 +213,8 @@ def load():
     L.bt_input_num_inputs.argtypes = [C.POINTER(InputDesc)]
     L.bt_input_max_active.argtypes = [C.POINTER(InputDesc)]
     L.bt_map_batch.argtypes = [C.POINTER(InputDesc), C.POINTER(MapOpts), C.c_void_p, C.c_int] + [C.c_void_p] * 5
+    L.bt_map_batch_device.argtypes = [C.c_void_p, C.POINTER(InputDesc), C.POINTER(MapOpts), C.c_void_p, C.c_int] + \
+        [C.c_void_p] * 5
     L.bt_net_init_weights_host.argtypes = [C.POINTER(NetDesc), C.c_uint64, C.c_int, C.c_void_p]
     L.bt_lr_at.restype = C.c_float
     L.bt_lr_at.argtypes = [C.POINTER(LrSched), C.c_int, C.c_int]
@@ -356,12 +358,12 @@ class Net:
 
     def train(self, input_desc, paths, batch_size, batches_per_superbatch, end_superbatch, lr, wdl, eval_scale=400.0,
               start_superbatch=1, out_buckets=1, threads=4, log_rate=0, win_rate_model=False, on_batch=None,
-              on_superbatch=None, wdl_output=False):
+              on_superbatch=None, wdl_output=False, device_mapper=False):
         """run::train through the C ABI. lr / wdl: LrSched / WdlSched. Returns [(superbatch, running_loss, pos/s)]."""
         import torch
         torch.cuda.synchronize()
         cfg = TrainConfig(batch_size, batches_per_superbatch, start_superbatch, end_superbatch, lr, wdl, eval_scale,
-                          out_buckets, int(win_rate_model), threads, log_rate, int(wdl_output))
+                          out_buckets, int(win_rate_model), threads, log_rate, int(wdl_output), int(device_mapper))
         report = []
 
         def sb_cb(_u, sb, loss, pps):

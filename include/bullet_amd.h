@@ -334,6 +334,12 @@ typedef struct {
  * weights F32[count]. Slots after the -1 terminator are left untouched (value.rs:86-89). */
 int bt_map_batch(const bt_input_desc *d, const bt_map_opts *o, const void *records, int count, int32_t *stm,
                  int32_t *nstm, int32_t *buckets, float *targets, float *weights);
+/* The same mapping on the device: records_dev (count*32 bytes, 8-byte aligned) and all outputs are DEVICE buffers;
+ * one wave per record, enqueued on `stream` (o->threads is ignored). Indices, terminators and buckets are
+ * bit-identical to bt_map_batch; score targets may differ by 1 ulp where the two exp implementations round
+ * differently. Only 32 B per position cross PCIe instead of 268 B, and no host thread touches the features. */
+int bt_map_batch_device(void *stream, const bt_input_desc *d, const bt_map_opts *o, const void *records_dev, int count,
+                        int32_t *stm, int32_t *nstm, int32_t *buckets, float *targets, float *weights);
 
 /* ------------------------------------------------------------------------------------------
  * 5. Weight init, schedules, data reader and the superbatch training loop
@@ -390,6 +396,8 @@ typedef struct {
     int log_rate;            /* progress line every log_rate batches (reference: 128); 0 = silent */
     int wdl_output;          /* ValueTrainerBuilder::wdl_output: 3-way one-hot targets (value.rs:96-101) for a net
                                 with loss_kind = BT_LOSS_SOFTMAX_CE and 3 outputs */
+    int device_mapper;       /* 1: the loader thread only reads records; they are uploaded raw and mapped by
+                                bt_map_batch_device on the copy stream (`threads` is then unused) */
 } bt_train_config;
 typedef void (*bt_batch_callback)(void *user, int superbatch, int batch, float loss);
 typedef void (*bt_superbatch_callback)(void *user, int superbatch, float running_loss, float positions_per_sec);

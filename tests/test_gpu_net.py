@@ -16,6 +16,8 @@ import oracle_binding as ob  # noqa: E402
 from bullet_amd import lib  # noqa: E402
 import gpu_util as gu  # noqa: E402
 
+L = lib.load()
+
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "batch.bf")
 MIRROR_LAYOUT = [0, 1, 2, 3, 4, 4, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8, 8, 8, 9, 9, 9, 9, 9, 9, 9, 9]
 
@@ -200,17 +202,7 @@ def test_other_loss_functions_net_vs_oracle(name):
 
 def test_ataxx_net_vs_oracle():
     """examples/ataxx.rs shape (F=147, N=49, H=256) on synthetic AtaxxBoard records."""
-    rng = np.random.default_rng(11)
-    n = 700
-    rec = np.zeros((n, 32), dtype=np.uint8)
-    for i in range(n):
-        sq = rng.permutation(49)
-        a, b, c = rng.integers(1, 22), rng.integers(1, 22), rng.integers(0, 5)
-        bbs = [sum(1 << int(s) for s in sq[:a]), sum(1 << int(s) for s in sq[a:a + b]),
-               sum(1 << int(s) for s in sq[a + b:a + b + c])]
-        rec[i, :24] = np.array(bbs, dtype=np.uint64).view(np.uint8)
-        rec[i, 24:26] = np.array([rng.integers(-1500, 1500)], dtype=np.int16).view(np.uint8)
-        rec[i, 26] = rng.integers(0, 3)
+    rec = _ataxx_records(700)
     batch = lib.map_batch(lib.make_input_desc("ataxx147"), rec.reshape(-1), blend=0.5)
     cfg = dict(num_inputs=147, nnz=49, ft_out=256, ft_act="screlu", dense=[(1, "identity", False)])
     r = run_steps(cfg, [batch], 3)
@@ -365,6 +357,76 @@ def test_train_run_king_bucketed_net_with_segment_promise():
     assert len(la) == 8 and la[0] == lb[0] and not any(np.isnan(la))
     np.testing.assert_allclose(la, lb, rtol=2e-5)
     torch.testing.assert_close(wa, wb, rtol=1e-4, atol=2e-5)
+
+
+def _ataxx_records(n, seed=11):
+    rng = np.random.default_rng(seed)
+    rec = np.zeros((n, 32), dtype=np.uint8)
+    for i in range(n):
+        sq = rng.permutation(49)
+        a, b, c = rng.integers(1, 22), rng.integers(1, 22), rng.integers(0, 5)
+        bbs = [sum(1 << int(s) for s in sq[:a]), sum(1 << int(s) for s in sq[a:a + b]),
+               sum(1 << int(s) for s in sq[a + b:a + b + c])]
+        rec[i, :24] = np.array(bbs, dtype=np.uint64).view(np.uint8)
+        rec[i, 24:26] = np.array([rng.integers(-1500, 1500)], dtype=np.int16).view(np.uint8)
+        rec[i, 26] = rng.integers(0, 3)
+    return rec
+
+
+MAPPER_CASES = [("chess768", None, False), ("chess768", None, True), ("chess_buckets", [i // 4 for i in range(64)], False),
+                ("chess_buckets_mirrored", MIRROR_LAYOUT, False), ("chess_buckets_mirrored", MIRROR_LAYOUT, True),
+                ("ataxx147", None, False), ("ataxx98", None, False)]
+
+
+@pytest.mark.parametrize("kind,layout,fact", MAPPER_CASES)
+@pytest.mark.parametrize("wdl,wrm", [(False, False), (False, True), (True, False)])
+def test_device_mapper_matches_host_mapper(kind, layout, fact, wdl, wrm):
+    """bt_map_batch_device vs bt_map_batch on every fixture record: indices, terminators, untouched tails and output
+    buckets bit-identical; score targets within 1 ulp (double-precision exp rounded to float vs the host's expf)."""
+    rec = _ataxx_records(3000) if kind.startswith("ataxx") else np.fromfile(GOLDEN, dtype=np.uint8).reshape(-1, 32)
+    n = rec.shape[0]
+    idesc = lib.make_input_desc(kind, fact, layout)
+    nnz = L.bt_input_max_active(C.byref(idesc))
+    host = (np.full((n, nnz), -7, np.int32), np.full((n, nnz), -7, np.int32), np.zeros(n, np.int32),
+            np.zeros(n * (3 if wdl else 1), np.float32), np.zeros(n, np.float32))
+    lib.map_batch(idesc, rec.reshape(-1).copy(), out_buckets=8, blend=0.3, win_rate_model=wrm, wdl=wdl, threads=4, out=host)
+    dev = [torch.full((n, nnz), -7, dtype=torch.int32, device="cuda"), torch.full((n, nnz), -7, dtype=torch.int32, device="cuda"),
+           torch.zeros(n, dtype=torch.int32, device="cuda"), torch.zeros(n * (3 if wdl else 1), device="cuda"),
+           torch.zeros(n, device="cuda")]
+    drec = gu.dev(rec.reshape(-1).copy())
+    o = lib.MapOpts(8, 0.3, 400.0, int(wrm), int(wdl), 1)
+    lib.check(L.bt_map_batch_device(gu.stream(), C.byref(idesc), C.byref(o), drec.data_ptr(), n,
+                                    *[t.data_ptr() for t in dev]))
+    torch.cuda.synchronize()
+    for name, h, d in zip(("stm", "nstm", "buckets"), host[:3], dev[:3]):
+        assert np.array_equal(h, d.cpu().numpy()), name
+    assert np.array_equal(host[4], dev[4].cpu().numpy())
+    if wdl:
+        assert np.array_equal(host[3], dev[3].cpu().numpy())
+    else:
+        np.testing.assert_array_max_ulp(host[3], dev[3].cpu().numpy(), maxulp=1)
+
+
+def test_train_run_device_mapper_matches_host_mapper():
+    """bt_train_run with device_mapper: raw records uploaded, mapped on the copy stream; same run as the host mapper"""
+    layout = [0, 0, 1, 1] * 2 + [2] * 8 + [3] * 16
+    idesc = lib.make_input_desc("chess_buckets_mirrored", False, layout)
+    lr, wdl = lib.LrSched(lib.LR["constant"], 0.001, 0, 0, 0), lib.WdlSched(lib.WDL["linear"], 0.2, 0.6, 0)
+    runs = []
+    for dm in (False, True):
+        cfg = dict(num_inputs=768 * 4, nnz=32, ft_out=64, ft_act="screlu", num_buckets=8, dense=[(1, "identity", True)],
+                   ft_segment=768)
+        net = lib.Net(lib.make_net_desc(**cfg), 2048)
+        net.init_weights(seed=3)
+        losses = []
+        net.train(idesc, [GOLDEN], 2048, 5, 2, lr, wdl, out_buckets=8, threads=2, device_mapper=dm,
+                  on_batch=lambda sb, b, l: losses.append(l))
+        runs.append((losses, net.params.clone()))
+        net.close()
+    (la, wa), (lb, wb) = runs
+    assert len(la) == 10
+    np.testing.assert_allclose(la, lb, rtol=1e-6)
+    torch.testing.assert_close(wa, wb, rtol=1e-5, atol=1e-7)
 
 
 def test_train_run_resume_matches_continuous_run(tmp_path):
