@@ -121,8 +121,9 @@ bool bt_internal_dense_head_ok(const bt_dense_desc *d);
 // mid-size bucketed layers walk the batch in bucket order when a (stable) permutation is installed for the calling
 // thread: wants_perm says whether a layer would use one, bucket_perm builds it, set_perm(nullptr) removes it
 bool bt_internal_dense_wants_perm(const bt_dense_desc *d);
-int bt_internal_bucket_perm(void *stream, const int32_t *bucket, int batch, int nb, int32_t *perm);
-void bt_internal_dense_set_perm(const int32_t *perm);
+size_t bt_internal_bucket_perm_bytes(int batch, int nb);
+int bt_internal_bucket_perm(void *stream, const int32_t *bucket, int batch, int nb, void *buf);
+void bt_internal_dense_set_perm(void *buf, int batch, int nb);
 // dense head forward fused with sigmoid-MSE: writes y, grad_y, per-workgroup loss partials and (optionally) gz_out =
 // grad_y * f'(y), the gradient w.r.t. the layer's pre-activation
 int bt_internal_dense_forward_loss(void *stream, const bt_dense_desc *d, const float *w, const float *bias,

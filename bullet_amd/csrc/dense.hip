@@ -687,11 +687,23 @@ constexpr int DM_OH = 8;        // output rows per workgroup, dW
 // positions holds all the buckets, and a chunk re-stages the bucket's 64 KiB of weights once per bucket present;
 // walking the batch in bucket order makes that once per chunk. net.hip builds the permutation once per step
 // (bucket_perm_kernel) and installs it for the calling thread; the public bt_dense_* entry points run without.
-thread_local const int32_t *g_dense_perm = nullptr;
+// The same kernel cuts the sorted order into bucket-pure items of <= DX_CH positions {bucket, start, count}; the
+// 16-output layers then run as small f32 GEMMs on the matrix cores, one item per workgroup (dense_mfma_*).
+struct DensePermTab {
+    const int32_t *perm = nullptr;  // [batch]
+    const int4 *items = nullptr;    // [max_items]
+    const int *bucket_items = nullptr;  // [nb + 1] item range of each bucket
+    const int *counts = nullptr;    // [0] number of items
+    int max_items = 0;
+};
+thread_local DensePermTab g_dense_tab;
+#define g_dense_perm (g_dense_tab.perm)
 constexpr int BP_THREADS = 1024;
+constexpr int DX_CH = 64;  // positions per item = 4 waves x one 16-row MFMA tile
 
 __global__ __launch_bounds__(BP_THREADS) void bucket_perm_kernel(const int32_t *__restrict__ bucket, int batch, int nb,
-                                                                 int32_t *__restrict__ perm) {
+                                                                 int32_t *__restrict__ perm, int4 *__restrict__ items,
+                                                                 int *__restrict__ bucket_items, int *__restrict__ counts) {
     extern __shared__ __align__(16) int bp_cnt[];  // [nb][BP_THREADS]: counts, then write cursors; then [batch] bytes
     __shared__ int wsum[BP_THREADS / 64];
     uint8_t *s_b = reinterpret_cast<uint8_t *>(bp_cnt + nb * BP_THREADS);  // the buckets, read once (coalesced)
@@ -722,7 +734,202 @@ __global__ __launch_bounds__(BP_THREADS) void bucket_perm_kernel(const int32_t *
         run += v;
     }
     __syncthreads();
+    // thread 0's cursors are the bucket starts (read before the placement below moves them)
+    __shared__ int s_start[17], s_istart[17];
+    if (t <= nb) s_start[t] = (t < nb) ? bp_cnt[t * BP_THREADS] : batch;
+    __syncthreads();
+    if (t == 0) {
+        int ni = 0;
+        for (int k = 0; k < nb; k++) {
+            s_istart[k] = bucket_items[k] = ni;
+            ni += (s_start[k + 1] - s_start[k] + DX_CH - 1) / DX_CH;
+        }
+        s_istart[nb] = bucket_items[nb] = counts[0] = ni;
+    }
+    __syncthreads();
+    for (int i = t; i < s_istart[nb]; i += BP_THREADS) {
+        int k = 0;
+        while (k + 1 < nb && s_istart[k + 1] <= i) k++;
+        const int o = s_start[k] + (i - s_istart[k]) * DX_CH;
+        items[i] = make_int4(k, o, min(DX_CH, s_start[k + 1] - o), 0);
+    }
     for (int p = p_lo; p < p_hi; p++) perm[bp_cnt[s_b[p] * BP_THREADS + t]++] = p;
+}
+
+// ---- 16 outputs per bucket (the first hidden layer of the multi-layer nets, (16 x buckets) x 1024): f32 MFMA
+// (v_mfma_f32_16x16x4_f32: exact f32, a k-ordered fma chain) on bucket-pure items. The reference computes all buckets
+// as one GEMM and discards all but one (matmul.rs:62-93 + select.rs:12-26); here an item multiplies its 64 positions
+// with its own bucket's 16 rows only, so the passes are bound by streaming x / grad_x (64 MiB at B = 16384) once.
+// Lane l of a wave: tile row/column l & 15, k = l >> 4; D: column l & 15, rows 4 (l >> 4) + r.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+bool dense_mfma_ok(const bt_dense_desc *d) {
+    return d->buckets > 1 && d->buckets <= 16 && d->out == 16 && d->in % 64 == 0 && d->in >= 64 && d->in <= 2048;
+}
+
+// y[pos][o] = f(W[bucket][o] . x[pos] + bias). 16 waves: wave (m, kq) multiplies the 16-position tile m with the kq-th
+// quarter of the inputs (W tile from LDS), so four waves per SIMD keep HBM requests in flight; the four partial tiles
+// of a position tile are added in the order kq = 0, 1, 2, 3 through LDS.
+constexpr int MF_THREADS = 1024;
+__global__ __launch_bounds__(MF_THREADS) void dense_mfma_fwd(const float *__restrict__ w, const float *__restrict__ bias,
+                                                             const float *__restrict__ x, float *__restrict__ y,
+                                                             bt_dense_desc d, DensePermTab tab) {
+    extern __shared__ __align__(16) float wt[];  // [16][in + 4]; afterwards the partial tiles [4 m][3 kq][64][4]
+    const int item = blockIdx.x;
+    if (item >= tab.counts[0]) return;
+    const int4 it = tab.items[item];
+    const int bk = it.x, start = it.y, cnt = it.z;
+    const int rows = d.out * d.buckets, ldw = d.in + 4;
+    for (int q = threadIdx.x; q < 4 * d.in; q += MF_THREADS) {  // (rows and bk * 16 are multiples of 4: 16-B aligned loads)
+        const int i = q >> 2, r4 = (q & 3) * 4;
+        const float4 v = *reinterpret_cast<const float4 *>(w + (size_t)rows * i + bk * 16 + r4);
+        wt[(r4 + 0) * ldw + i] = v.x, wt[(r4 + 1) * ldw + i] = v.y, wt[(r4 + 2) * ldw + i] = v.z, wt[(r4 + 3) * ldw + i] = v.w;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, qd = lane >> 4;
+    const int m = wave & 3, kq = wave >> 2;
+    const int pos = tab.perm[start + min(16 * m + n, cnt - 1)];
+    const int nk = d.in / 64;  // k-blocks of 16 per quarter (in % 64 == 0)
+    const float4 *xr = reinterpret_cast<const float4 *>(x + (size_t)pos * d.in) + qd + 4 * kq * nk;
+    const float4 *wr = reinterpret_cast<const float4 *>(wt + n * ldw) + qd + 4 * kq * nk;
+    f32x4_t acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    // k = 16 t + 4 qd + j on both operands (any consistent k order gives the same set of products)
+    for (int t = 0; t < nk; t++) {
+        const float4 a = xr[4 * t], b = wr[4 * t];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc1, 0, 0, 0);
+    }
+    f32x4_t acc = acc0 + acc1;
+    __syncthreads();  // every wave is done with the W tile
+    f32x4_t *red = reinterpret_cast<f32x4_t *>(wt);
+    if (kq > 0) red[(m * 3 + kq - 1) * 64 + lane] = acc;
+    __syncthreads();
+    if (kq > 0) return;
+    for (int k2 = 0; k2 < 3; k2++) acc += red[(m * 3 + k2) * 64 + lane];
+    const float bias_n = bias[bk * 16 + n];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int pl = 16 * m + 4 * qd + r;
+        if (pl < cnt) y[(size_t)tab.perm[start + pl] * 16 + n] = bt_act_fwd(d.act, acc[r] + bias_n);
+    }
+}
+
+// gx[pos][i] = sum_o W[bucket][o][i] * gz[pos][o]: K = the 16 outputs (one MFMA quad per 16 x 16 tile); a wave keeps
+// the gz fragments of the item's four position tiles and walks its quarter of the input columns
+__global__ __launch_bounds__(256) void dense_mfma_dx(const float *__restrict__ w, const float *__restrict__ gz,
+                                                     float *__restrict__ gx, bt_dense_desc d, DensePermTab tab) {
+    __shared__ int s_pos[DX_CH];
+    const int item = blockIdx.x;
+    if (item >= tab.counts[0]) return;
+    const int4 it = tab.items[item];
+    const int bk = it.x, start = it.y, cnt = it.z;
+    const int rows = d.out * d.buckets;
+    if ((int)threadIdx.x < DX_CH) s_pos[threadIdx.x] = tab.perm[start + min((int)threadIdx.x, cnt - 1)];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, qd = lane >> 4;
+    float4 a[4];  // A[position 16 m + n][o = 4 qd + j]
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        a[m] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (16 * m + n < cnt) a[m] = *reinterpret_cast<const float4 *>(gz + (size_t)s_pos[16 * m + n] * 16 + 4 * qd);
+    }
+    const int ntile = d.in / 16, per = (ntile + 3) / 4;
+    for (int nt = wave * per; nt < min(ntile, (wave + 1) * per); nt++) {
+        // B[o = 4 qd + j][i = 16 nt + n]: four consecutive rows of W's column i
+        const float4 b = *reinterpret_cast<const float4 *>(w + (size_t)rows * (16 * nt + n) + bk * 16 + 4 * qd);
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            if (16 * m >= cnt) break;
+            f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, b.w, acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int pl = 16 * m + 4 * qd + r;
+                if (pl < cnt) gx[(size_t)s_pos[pl] * d.in + 16 * nt + n] = acc[r];
+            }
+        }
+    }
+}
+
+// part_w[item][o][i] = sum over the item's positions of gz[pos][o] * x[pos][i]; part_b[item][o] = sum of gz[pos][o].
+// K = positions, 4 per MFMA; a lane reads x as float4 and feeds register j to the tile of columns 64 T + 4 n + j,
+// so one 256-B row segment serves four MFMAs. A wave owns a quarter of the 64-column blocks T.
+template <int TW>
+__global__ __launch_bounds__(256) void dense_mfma_dw(const float *__restrict__ x, const float *__restrict__ gz,
+                                                     float *__restrict__ part_w, float *__restrict__ part_b,
+                                                     bt_dense_desc d, DensePermTab tab) {
+    __shared__ int s_pos[DX_CH];
+    const int item = blockIdx.x;
+    if (item >= tab.counts[0]) return;
+    const int4 it = tab.items[item];
+    const int start = it.y, cnt = it.z;
+    if ((int)threadIdx.x < DX_CH) s_pos[threadIdx.x] = tab.perm[start + min((int)threadIdx.x, cnt - 1)];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, qd = lane >> 4;
+    const int nT = d.in / 64, T0 = wave * TW;
+    f32x4_t acc[TW][4], accb = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int t = 0; t < TW; t++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[t][j] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int p0 = 0; p0 < cnt; p0 += 4) {
+        const int p = p0 + qd;
+        const bool live = p < cnt;
+        const int pos = s_pos[min(p, cnt - 1)];
+        const float av = live ? gz[(size_t)pos * 16 + n] : 0.0f;  // A[o = n][k = position p0 + qd]
+        const float *xr = x + (size_t)pos * d.in + 4 * n;
+        float4 b[TW];
+#pragma unroll
+        for (int t = 0; t < TW; t++)
+            b[t] = (T0 + t < nT) ? *reinterpret_cast<const float4 *>(xr + 64 * (T0 + t)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int t = 0; t < TW; t++) {
+            acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[t].x, acc[t][0], 0, 0, 0);
+            acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[t].y, acc[t][1], 0, 0, 0);
+            acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[t].z, acc[t][2], 0, 0, 0);
+            acc[t][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[t].w, acc[t][3], 0, 0, 0);
+        }
+        if (wave == 0) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(av, 1.0f, accb, 0, 0, 0);  // every column = sum of gz
+    }
+    float *pw = part_w + (size_t)item * 16 * d.in;
+#pragma unroll
+    for (int t = 0; t < TW; t++) {
+        if (T0 + t >= nT) break;
+#pragma unroll
+        for (int r = 0; r < 4; r++)  // D row o = 4 qd + r; columns 64 T + 4 n + j, j = 0..3
+            *reinterpret_cast<float4 *>(pw + (size_t)(4 * qd + r) * d.in + 64 * (T0 + t) + 4 * n) =
+                make_float4(acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]);
+    }
+    if (wave == 0 && n == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) part_b[(size_t)item * 16 + 4 * qd + r] = accb[r];
+    }
+}
+
+// dw[bucket*16 + o][i] = sum of the bucket's item partials in list order (zeros for a bucket without positions)
+__global__ __launch_bounds__(256) void dense_mfma_sum(const float *__restrict__ part_w, const float *__restrict__ part_b,
+                                                      float *__restrict__ dw, float *__restrict__ dbias, bt_dense_desc d,
+                                                      DensePermTab tab) {
+    const int rows = d.out * d.buckets;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nw = (size_t)rows * d.in;
+    if (t < nw) {
+        const int row = (int)(t / d.in), i = (int)(t - (size_t)row * d.in);
+        const int bk = row >> 4, o = row & 15;
+        float s = 0.0f;
+        for (int g = tab.bucket_items[bk]; g < tab.bucket_items[bk + 1]; g++) s += part_w[((size_t)g * 16 + o) * d.in + i];
+        dw[(size_t)rows * i + row] = s;
+    } else if (t < nw + rows) {
+        const int row = (int)(t - nw), bk = row >> 4, o = row & 15;
+        float s = 0.0f;
+        for (int g = tab.bucket_items[bk]; g < tab.bucket_items[bk + 1]; g++) s += part_b[(size_t)g * 16 + o];
+        dbias[row] = s;
+    }
 }
 
 bool dense_mid_ok(const bt_dense_desc *d) {
@@ -1133,15 +1340,38 @@ bool bt_internal_dense_wants_perm(const bt_dense_desc *d) {
     return dense_validate(d, "dense_wants_perm") == BT_OK && d->buckets > 1 && d->buckets <= 16 && !dense_fwd_small_ok(d) &&
            dense_mid_ok(d);
 }
-int bt_internal_bucket_perm(void *stream, const int32_t *bucket, int batch, int nb, int32_t *perm) {
-    BT_REQUIRE(bucket && perm && batch > 0 && batch <= 64 * 1024 && nb > 1 && nb <= 16, "bucket_perm: bad arguments");
+// layout of the permutation buffer: perm [batch] | items int4[batch / DX_CH + nb] | bucket_items [nb + 1] | counts [4]
+static DensePermTab dense_perm_tab(void *buf, int batch, int nb) {
+    DensePermTab t;
+    char *p = static_cast<char *>(buf);
+    t.max_items = bt_div_up(batch, DX_CH) + nb;
+    t.perm = reinterpret_cast<const int32_t *>(p);
+    p += bt_align((size_t)batch * sizeof(int32_t));
+    t.items = reinterpret_cast<const int4 *>(p);
+    p += bt_align((size_t)t.max_items * sizeof(int4));
+    t.bucket_items = reinterpret_cast<const int *>(p);
+    p += bt_align((size_t)(nb + 1) * sizeof(int));
+    t.counts = reinterpret_cast<const int *>(p);
+    return t;
+}
+size_t bt_internal_bucket_perm_bytes(int batch, int nb) {
+    return bt_align((size_t)batch * sizeof(int32_t)) + bt_align((size_t)(bt_div_up(batch, DX_CH) + nb) * sizeof(int4)) +
+           bt_align((size_t)(nb + 1) * sizeof(int)) + bt_align(4 * sizeof(int));
+}
+int bt_internal_bucket_perm(void *stream, const int32_t *bucket, int batch, int nb, void *buf) {
+    BT_REQUIRE(bucket && buf && batch > 0 && batch <= 64 * 1024 && nb > 1 && nb <= 16, "bucket_perm: bad arguments");
     const size_t lds = (size_t)nb * BP_THREADS * sizeof(int) + bt_align((size_t)batch, 16);
     if (int rc = dense_set_lds(bucket_perm_kernel, lds)) return rc;
-    BT_LAUNCH(BTK_DENSE_FWD, bt_stream(stream), bucket_perm_kernel, dim3(1), dim3(BP_THREADS), lds, bucket, batch, nb, perm);
+    const DensePermTab t = dense_perm_tab(buf, batch, nb);
+    BT_LAUNCH(BTK_DENSE_FWD, bt_stream(stream), bucket_perm_kernel, dim3(1), dim3(BP_THREADS), lds, bucket, batch, nb,
+              const_cast<int32_t *>(t.perm), const_cast<int4 *>(t.items), const_cast<int *>(t.bucket_items),
+              const_cast<int *>(t.counts));
     BT_LAUNCH_CHECK();
     return BT_OK;
 }
-void bt_internal_dense_set_perm(const int32_t *perm) { g_dense_perm = perm; }
+void bt_internal_dense_set_perm(void *buf, int batch, int nb) {
+    g_dense_tab = buf ? dense_perm_tab(buf, batch, nb) : DensePermTab();
+}
 
 bool bt_internal_dense_head_ok(const bt_dense_desc *d) { return dense_validate(d, "dense_head_ok") == BT_OK && dense_bwd_small_ok(d); }
 
@@ -1202,6 +1432,14 @@ int bt_dense_forward(void *stream, const bt_dense_desc *d, const float *w, const
     BT_REQUIRE(w && bias && x && y, "bt_dense_forward: null pointer");
     BT_REQUIRE(d->buckets == 1 || bucket, "bt_dense_forward: bucketed layer needs bucket indices");
     if (dense_fwd_small_ok(d)) return dense_fwd_small_launch(bt_stream(stream), d, w, bias, x, bucket, y, nullptr, nullptr);
+    if (dense_mfma_ok(d) && g_dense_tab.items && !dense_fwd_small_ok(d)) {
+        const size_t lds = (size_t)16 * (d->in + 4) * sizeof(float);
+        if (int rc = dense_set_lds(dense_mfma_fwd, lds)) return rc;
+        BT_LAUNCH(BTK_DENSE_FWD, bt_stream(stream), dense_mfma_fwd, dim3(g_dense_tab.max_items), dim3(MF_THREADS), lds, w, bias, x, y,
+                  *d, g_dense_tab);
+        BT_LAUNCH_CHECK();
+        return BT_OK;
+    }
     if (dense_mid_ok(d)) return dense_mid_launch(bt_stream(stream), d, w, bias, x, bucket, y, false);
     if (dense_tiny_ok(d)) {
         BT_LAUNCH(BTK_DENSE_FWD, bt_stream(stream), dense_tiny_fwd_kernel, dim3(bt_div_up((long long)d->batch * d->out, 256)),
@@ -1253,6 +1491,26 @@ int bt_dense_backward(void *stream, const bt_dense_desc *d, const float *w, cons
         BT_LAUNCH(BTK_DENSE_BWD_DX, s, dense_gz_kernel, dim3(bt_div_up((long long)ngz, 256)), dim3(256), 0, y, grad_y, gz, ngz,
                   d->act);
         BT_LAUNCH_CHECK();
+        if (!tiny && dense_mfma_ok(d) && g_dense_tab.items &&
+            (size_t)g_dense_tab.max_items * 16 * d->in <= (size_t)nrm * rows * d->in) {
+            const DensePermTab tab = g_dense_tab;
+            if (grad_x) {
+                BT_LAUNCH(BTK_DENSE_BWD_DX, s, dense_mfma_dx, dim3(tab.max_items), dim3(256), 0, w, gz, grad_x, *d, tab);
+                BT_LAUNCH_CHECK();
+            }
+            const int tw = bt_div_up(d->in / 64, 4);  // 64-column blocks per wave: up to 8 (in <= 2048)
+#define MDW(TW)                                                                                                      \
+    case TW:                                                                                                         \
+        BT_LAUNCH(BTK_DENSE_BWD_DW, s, dense_mfma_dw<TW>, dim3(tab.max_items), dim3(256), 0, x, gz, pw, pb, *d, tab);  \
+        break;
+            switch (tw) { MDW(1) MDW(2) MDW(3) MDW(4) MDW(5) MDW(6) MDW(7) MDW(8) }
+#undef MDW
+            BT_LAUNCH_CHECK();
+            BT_LAUNCH(BTK_SUM_PARTIALS, s, dense_mfma_sum, dim3(bt_div_up((long long)rows * d->in + rows, 256)), dim3(256), 0,
+                      pw, pb, dw, dbias, *d, tab);
+            BT_LAUNCH_CHECK();
+            return BT_OK;
+        }
         if (tiny) {
             if (grad_x) {
                 BT_LAUNCH(BTK_DENSE_BWD_DX, s, dense_tiny_dx_kernel, dim3(bt_div_up((long long)d->batch * d->in, 256)),

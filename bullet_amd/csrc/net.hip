@@ -37,7 +37,7 @@ struct bt_net {
     // gzp[k] the gradient w.r.t. z; yfin = last layer + skip neurons; weff = l0w + l0f.repeat(NB)
     float *ap[BT_MAX_DENSE] = {nullptr}, *gzp[BT_MAX_DENSE] = {nullptr};
     float *yfin = nullptr, *weff = nullptr;
-    int32_t *perm = nullptr;  // [B] positions in output-bucket order for the mid-size bucketed layers (dense.hip)
+    void *perm = nullptr;  // positions in output-bucket order + bucket-pure items for the bucketed layers (dense.hip)
     void *ft_ws = nullptr, *dense_ws = nullptr;
     // side stream: the FT sorted index (depends only on the batch indices) is built while the forward runs
     hipStream_t side = nullptr;
@@ -211,9 +211,9 @@ struct PermScope {
     PermScope(bt_net *n, hipStream_t s, const bt_batch *b) {
         if (!n->perm || !b->buckets || b->batch > 64 * 1024) return;
         rc = bt_internal_bucket_perm(s, b->buckets, b->batch, n->d.num_buckets, n->perm);
-        if (rc == BT_OK) bt_internal_dense_set_perm(n->perm), built = true;
+        if (rc == BT_OK) bt_internal_dense_set_perm(n->perm, b->batch, n->d.num_buckets), built = true;
     }
-    ~PermScope() { bt_internal_dense_set_perm(nullptr); }
+    ~PermScope() { bt_internal_dense_set_perm(nullptr, 0, 0); }
 };
 
 // groups_ready: the segment entry lists of this batch are already in ft_ws (bt_net_forward_backward builds them
@@ -382,7 +382,7 @@ int bt_net_create(const bt_net_desc *desc, int max_batch, float *ext_params, flo
     for (int k = 0; k < desc->n_dense && !n->perm; k++) {
         bt_dense_desc q = dn_desc(n, k, max_batch);
         if (bt_internal_dense_wants_perm(&q))
-            if ((rc = bt_malloc(reinterpret_cast<void **>(&n->perm), B * sizeof(int32_t)))) return fail(rc);
+            if ((rc = bt_malloc(&n->perm, bt_internal_bucket_perm_bytes(max_batch, desc->num_buckets)))) return fail(rc);
     }
     bt_ft_desc f = ft_desc(n, max_batch);
     n->ft_ws_bytes = bt_ft_backward_workspace_bytes(&f);

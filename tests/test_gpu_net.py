@@ -135,6 +135,10 @@ NETS = {
     "factoriser_single_layer": (dict(num_inputs=768 * 4, nnz=32, ft_out=256, ft_act="screlu", num_buckets=8,
                                      ft_factoriser=4, dense=[(1, "identity", True)]),
                                 ("chess_buckets_mirrored", [0, 0, 1, 1] * 2 + [2] * 8 + [3] * 16, False), 8, 0),
+    # a 16-output bucketed first layer over 1536 inputs (the H = 1536 variant of BASELINE configs[3]): f32-MFMA kernels
+    # with six 64-column blocks per wave in the weight-gradient pass
+    "l1_in1536_mfma": (dict(num_inputs=768, nnz=32, ft_out=768, ft_act="crelu", num_buckets=8,
+                            dense=[(16, "screlu", True), (1, "identity", True)]), ("chess768", None, False), 8, 0),
     "single_perspective": (dict(num_inputs=768, nnz=32, ft_out=64, ft_act="crelu", perspectives=1,
                                 dense=[(8, "relu", False), (1, "identity", False)], use_entry_weights=True),
                            ("chess768", None, False), 1, 0),
