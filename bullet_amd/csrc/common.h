@@ -124,6 +124,14 @@ bool bt_internal_dense_wants_perm(const bt_dense_desc *d);
 size_t bt_internal_bucket_perm_bytes(int batch, int nb);
 int bt_internal_bucket_perm(void *stream, const int32_t *bucket, int batch, int nb, void *buf);
 void bt_internal_dense_set_perm(void *buf, int batch, int nb);
+// the two last (tiny, bucketed) layers + sigmoid-MSE + their backward pass in one kernel over the installed
+// permutation's items: y [B], ga1 = gradient w.r.t. the activated input a1 [B][q1->in], all four gradients, loss sum
+bool bt_internal_dense_tail_ok(const bt_dense_desc *q1, const bt_dense_desc *q2);
+size_t bt_internal_dense_tail_workspace_bytes(const bt_dense_desc *q1);
+int bt_internal_dense_tail(void *stream, const bt_dense_desc *q1, const bt_dense_desc *q2, const float *w2, const float *b2,
+                           const float *w3, const float *b3, const float *a1, const float *targets, const float *ew,
+                           float *y, float *ga1, float *dw2, float *db2, float *dw3, float *db3, float *loss_sum,
+                           void *workspace, size_t workspace_bytes);
 // dense head forward fused with sigmoid-MSE: writes y, grad_y, per-workgroup loss partials and (optionally) gz_out =
 // grad_y * f'(y), the gradient w.r.t. the layer's pre-activation
 int bt_internal_dense_forward_loss(void *stream, const bt_dense_desc *d, const float *w, const float *bias,

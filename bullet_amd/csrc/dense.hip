@@ -911,24 +911,190 @@ __global__ __launch_bounds__(256) void dense_mfma_dw(const float *__restrict__ x
     }
 }
 
-// dw[bucket*16 + o][i] = sum of the bucket's item partials in list order (zeros for a bucket without positions)
+// Sum of element e over the items [lo, hi) of one bucket, for a 256-thread block laid out as 32 elements x 8 slices:
+// slice s adds items lo + s, lo + s + 8, ... in ascending order, the eight slice sums are then added in slice order.
+// The order depends only on the item list, so results are bit-identical run to run; with every position in one
+// bucket (hundreds of items) the chain per thread is 8 times shorter than a plain loop.
+__device__ __forceinline__ float sliced_item_sum(const float *__restrict__ part, size_t item_stride, size_t e, int lo,
+                                                 int hi, bool live, float *red /* [8][32] */) {
+    const int el = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    float s = 0.0f;
+    if (live)
+        for (int g = lo + slice; g < hi; g += 8) s += part[(size_t)g * item_stride + e];
+    red[slice * 32 + el] = s;
+    __syncthreads();
+    float tot = 0.0f;
+    if (slice == 0)
+        for (int k = 0; k < 8; k++) tot += red[k * 32 + el];
+    return tot;  // valid on slice 0
+}
+
+// dw[bucket*16 + o][i] = sum of the bucket's item partials (zeros for a bucket without positions); grid (ceil((16 in + 16) / 32), nb)
 __global__ __launch_bounds__(256) void dense_mfma_sum(const float *__restrict__ part_w, const float *__restrict__ part_b,
                                                       float *__restrict__ dw, float *__restrict__ dbias, bt_dense_desc d,
                                                       DensePermTab tab) {
-    const int rows = d.out * d.buckets;
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t nw = (size_t)rows * d.in;
-    if (t < nw) {
-        const int row = (int)(t / d.in), i = (int)(t - (size_t)row * d.in);
-        const int bk = row >> 4, o = row & 15;
+    __shared__ float red[256];
+    const int rows = d.out * d.buckets, bk = blockIdx.y;
+    const int e = blockIdx.x * 32 + (threadIdx.x & 31), nw = 16 * d.in;
+    const int lo = tab.bucket_items[bk], hi = tab.bucket_items[bk + 1];
+    const bool isw = e < nw, isb = !isw && e < nw + 16;
+    const float tot = sliced_item_sum(isw ? part_w : part_b, isw ? (size_t)16 * d.in : 16, isw ? e : e - nw, lo, hi,
+                                      isw || isb, red);
+    if ((threadIdx.x >> 5) != 0) return;
+    if (isw) {
+        const int o = e / d.in, i = e - o * d.in;
+        dw[(size_t)rows * i + bk * 16 + o] = tot;
+    } else if (isb) {
+        dbias[bk * 16 + (e - nw)] = tot;
+    }
+}
+
+// ---- fused tail of the multi-layer nets (examples/progression/4_multi_layer.rs: ... -> 16 -> 32 -> 1, all
+// bucketed): the two last layers, the sigmoid-MSE loss and their whole backward pass for one bucket-pure item of 64
+// positions in one workgroup. Everything between the first hidden layer's output a1 and the gradient w.r.t. a1 stays
+// in LDS; thirteen small launches of the layer-by-layer path become two (this kernel + dense_tail_sum).
+// Per-position arithmetic is the same as the layer kernels' (dot products in ascending input order from 0.0f, bias
+// added last, derivatives from outputs); weight gradients are summed position by position inside an item and item by
+// item (list order) per bucket.
+constexpr int TAIL_THREADS = 256;
+struct TailArgs {
+    const float *w2, *b2, *w3, *b3;     // layer A: [(n2*nb) x n1] column-major, layer B: [nb x n2]
+    const float *a1;                    // [B][n1] activated output of the layer before
+    const float *targets, *ew;          // ew may be null
+    float *y, *ga1;                     // net output [B], gradient w.r.t. a1 [B][n1]
+    float *part;                        // [max_items][tail_part_floats]
+    int n1, n2, nb, act2, act3;
+};
+__host__ __device__ inline int tail_part_floats(int n1, int n2) { return n2 * n1 + 2 * n2 + 2; }  // dW2 db2 dW3 db3 loss
+
+__global__ __launch_bounds__(TAIL_THREADS) void dense_tail_kernel(TailArgs A, DensePermTab tab) {
+    extern __shared__ __align__(16) float tl[];
+    const int item = blockIdx.x;
+    if (item >= tab.counts[0]) return;
+    const int4 it = tab.items[item];
+    const int bk = it.x, start = it.y, cnt = it.z;
+    const int n1 = A.n1, n2 = A.n2, l1 = n1 + 1, l2 = n2 + 1;
+    float *W2 = tl;                      // [n2][n1]
+    float *B2 = W2 + n2 * n1;            // [n2]
+    float *W3 = B2 + n2;                 // [n2]
+    float *a1 = W3 + n2;                 // [64][n1 + 1]
+    float *a2 = a1 + DX_CH * l1;         // [64][n2 + 1]
+    float *g2 = a2 + DX_CH * l2;         // [64][n2 + 1]  gradient w.r.t. layer A's pre-activation
+    float *g3 = g2 + DX_CH * l2;         // [64]          gradient w.r.t. layer B's pre-activation
+    float *ls = g3 + DX_CH;              // [64]          loss terms
+    __shared__ int s_pos[DX_CH];
+    const int t = threadIdx.x, rows2 = n2 * A.nb;
+    if (t < DX_CH) s_pos[t] = tab.perm[start + min(t, cnt - 1)];
+    for (int q = t; q < n2 * n1; q += TAIL_THREADS) {
+        const int o = q % n2, i = q / n2;
+        W2[o * n1 + i] = A.w2[(size_t)rows2 * i + bk * n2 + o];
+    }
+    for (int q = t; q < n2; q += TAIL_THREADS) B2[q] = A.b2[bk * n2 + q], W3[q] = A.w3[(size_t)A.nb * q + bk];
+    __syncthreads();
+    for (int q = t; q < DX_CH * n1; q += TAIL_THREADS) {
+        const int p = q / n1, i = q - p * n1;
+        a1[p * l1 + i] = A.a1[(size_t)s_pos[p] * n1 + i];
+    }
+    __syncthreads();
+    // layer A forward
+    for (int q = t; q < DX_CH * n2; q += TAIL_THREADS) {
+        const int p = q & (DX_CH - 1), o = q / DX_CH;
+        float z = 0.0f;
+        for (int i = 0; i < n1; i++) z += W2[o * n1 + i] * a1[p * l1 + i];
+        a2[p * l2 + o] = bt_act_fwd(A.act2, z + B2[o]);
+    }
+    __syncthreads();
+    // layer B forward, loss, gradient of the loss (same arithmetic as sigmoid_mse_kernel)
+    if (t < DX_CH) {
+        float l = 0.0f, gz = 0.0f;
+        if (t < cnt) {
+            float z = 0.0f;
+            for (int i = 0; i < n2; i++) z += W3[i] * a2[t * l2 + i];
+            const float yv = bt_act_fwd(A.act3, z + A.b3[bk]);
+            const int pos = s_pos[t];
+            A.y[pos] = yv;
+            const float sg = 1.0f / (1.0f + expf(-1.0f * yv));
+            const float diff = sg + (-1.0f * A.targets[pos]);
+            const float g = A.ew ? A.ew[pos] : 1.0f;
+            l = diff * diff;
+            if (A.ew) l = g * l;
+            const float dd = g * diff + g * diff;
+            gz = (dd * (sg * (1.0f + (-1.0f * sg)))) * bt_act_deriv(A.act3, yv);
+        }
+        g3[t] = gz, ls[t] = l;
+    }
+    __syncthreads();
+    // layer B backward (dX = W3 * gz, one output) and layer A's activation derivative
+    for (int q = t; q < DX_CH * n2; q += TAIL_THREADS) {
+        const int p = q & (DX_CH - 1), o = q / DX_CH;
+        g2[p * l2 + o] = (W3[o] * g3[p]) * bt_act_deriv(A.act2, a2[p * l2 + o]);
+    }
+    __syncthreads();
+    // layer A dX -> gradient w.r.t. a1
+    for (int q = t; q < DX_CH * n1; q += TAIL_THREADS) {
+        const int p = q / n1, i = q - p * n1;
+        if (p < cnt) {
+            float sacc = 0.0f;
+            for (int o = 0; o < n2; o++) sacc += W2[o * n1 + i] * g2[p * l2 + o];
+            A.ga1[(size_t)s_pos[p] * n1 + i] = sacc;
+        }
+    }
+    // weight-gradient partials of the item (positions beyond cnt hold zero gradients)
+    float *part = A.part + (size_t)item * tail_part_floats(n1, n2);
+    for (int q = t; q < n2 * n1; q += TAIL_THREADS) {
+        const int o = q / n1, i = q - o * n1;
+        float sacc = 0.0f;
+        for (int p = 0; p < DX_CH; p++) sacc += g2[p * l2 + o] * a1[p * l1 + i];
+        part[q] = sacc;
+    }
+    for (int q = t; q < n2; q += TAIL_THREADS) {
+        float sb = 0.0f, sw = 0.0f;
+        for (int p = 0; p < DX_CH; p++) sb += g2[p * l2 + q], sw += g3[p] * a2[p * l2 + q];
+        part[n2 * n1 + q] = sb, part[n2 * n1 + n2 + q] = sw;
+    }
+    if (t == TAIL_THREADS - 1) {
+        float sb = 0.0f, sl = 0.0f;
+        for (int p = 0; p < DX_CH; p++) sb += g3[p], sl += ls[p];
+        part[n2 * n1 + 2 * n2] = sb, part[n2 * n1 + 2 * n2 + 1] = sl;
+    }
+}
+
+// gradients of both tail layers = per-bucket sums of the item partials; grid (ceil(per-bucket elements / 32), nb + 1):
+// the extra row of blocks adds up the loss terms of all items
+__global__ __launch_bounds__(256) void dense_tail_sum(const float *__restrict__ part, int n1, int n2, int nb,
+                                                      float *__restrict__ dw2, float *__restrict__ db2,
+                                                      float *__restrict__ dw3, float *__restrict__ db3,
+                                                      float *__restrict__ loss_sum, DensePermTab tab) {
+    __shared__ float red[256];
+    const int P = tail_part_floats(n1, n2), per_b = P - 1;
+    const int bk = blockIdx.y;
+    if (bk == nb) {  // loss: element P - 1 of every item
+        if (blockIdx.x != 0) return;
+        const int ni = tab.counts[0];
         float s = 0.0f;
-        for (int g = tab.bucket_items[bk]; g < tab.bucket_items[bk + 1]; g++) s += part_w[((size_t)g * 16 + o) * d.in + i];
-        dw[(size_t)rows * i + row] = s;
-    } else if (t < nw + rows) {
-        const int row = (int)(t - nw), bk = row >> 4, o = row & 15;
-        float s = 0.0f;
-        for (int g = tab.bucket_items[bk]; g < tab.bucket_items[bk + 1]; g++) s += part_b[(size_t)g * 16 + o];
-        dbias[row] = s;
+        for (int g = threadIdx.x; g < ni; g += 256) s += part[(size_t)g * P + P - 1];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) loss_sum[0] = red[0];
+        return;
+    }
+    const int e = blockIdx.x * 32 + (threadIdx.x & 31);
+    const float s = sliced_item_sum(part, (size_t)P, (size_t)e, tab.bucket_items[bk], tab.bucket_items[bk + 1], e < per_b, red);
+    if ((threadIdx.x >> 5) != 0 || e >= per_b) return;
+    const int rows2 = n2 * nb;
+    if (e < n2 * n1) {
+        const int o = e / n1, i = e - o * n1;
+        dw2[(size_t)rows2 * i + bk * n2 + o] = s;
+    } else if (e < n2 * n1 + n2) {
+        db2[bk * n2 + (e - n2 * n1)] = s;
+    } else if (e < n2 * n1 + 2 * n2) {
+        dw3[(size_t)nb * (e - n2 * n1 - n2) + bk] = s;
+    } else {
+        db3[bk] = s;
     }
 }
 
@@ -1369,6 +1535,37 @@ int bt_internal_bucket_perm(void *stream, const int32_t *bucket, int batch, int 
     BT_LAUNCH_CHECK();
     return BT_OK;
 }
+// fused tail (see dense_tail_kernel): q1 = the layer before the last, q2 = the last layer
+bool bt_internal_dense_tail_ok(const bt_dense_desc *q1, const bt_dense_desc *q2) {
+    return q1 && q2 && q1->buckets > 1 && q1->buckets <= 16 && q2->buckets == q1->buckets && q2->out == 1 &&
+           q2->in == q1->out && q1->in >= 1 && q1->in <= 64 && q1->out >= 1 && q1->out <= 64 && q1->batch == q2->batch;
+}
+size_t bt_internal_dense_tail_workspace_bytes(const bt_dense_desc *q1) {
+    return (size_t)(bt_div_up(q1->batch, DX_CH) + q1->buckets) * tail_part_floats(q1->in, q1->out) * sizeof(float);
+}
+int bt_internal_dense_tail(void *stream, const bt_dense_desc *q1, const bt_dense_desc *q2, const float *w2, const float *b2,
+                           const float *w3, const float *b3, const float *a1, const float *targets, const float *ew,
+                           float *y, float *ga1, float *dw2, float *db2, float *dw3, float *db3, float *loss_sum,
+                           void *workspace, size_t workspace_bytes) {
+    BT_REQUIRE(bt_internal_dense_tail_ok(q1, q2), "dense_tail: shape not supported");
+    BT_REQUIRE(g_dense_tab.items, "dense_tail: no bucket permutation installed");
+    BT_REQUIRE(w2 && b2 && w3 && b3 && a1 && targets && y && ga1 && dw2 && db2 && dw3 && db3 && loss_sum && workspace,
+               "dense_tail: null pointer");
+    BT_REQUIRE(workspace_bytes >= bt_internal_dense_tail_workspace_bytes(q1), "dense_tail: workspace too small");
+    const DensePermTab tab = g_dense_tab;
+    const int n1 = q1->in, n2 = q1->out, nb = q1->buckets;
+    TailArgs A{w2, b2, w3, b3, a1, targets, ew, y, ga1, static_cast<float *>(workspace), n1, n2, nb, q1->act, q2->act};
+    const size_t lds = ((size_t)n2 * n1 + 2 * n2 + DX_CH * (n1 + 1) + 2 * DX_CH * (n2 + 1) + 2 * DX_CH) * sizeof(float);
+    hipStream_t s = bt_stream(stream);
+    if (int rc = dense_set_lds(dense_tail_kernel, lds)) return rc;
+    BT_LAUNCH(BTK_DENSE_BWD_SMALL, s, dense_tail_kernel, dim3(tab.max_items), dim3(TAIL_THREADS), lds, A, tab);
+    BT_LAUNCH_CHECK();
+    BT_LAUNCH(BTK_SUM_PARTIALS, s, dense_tail_sum, dim3(bt_div_up(tail_part_floats(n1, n2) - 1, 32), nb + 1), dim3(256), 0,
+              A.part, n1, n2, nb, dw2, db2, dw3, db3, loss_sum, tab);
+    BT_LAUNCH_CHECK();
+    return BT_OK;
+}
+
 void bt_internal_dense_set_perm(void *buf, int batch, int nb) {
     g_dense_tab = buf ? dense_perm_tab(buf, batch, nb) : DensePermTab();
 }
@@ -1506,7 +1703,7 @@ int bt_dense_backward(void *stream, const bt_dense_desc *d, const float *w, cons
             switch (tw) { MDW(1) MDW(2) MDW(3) MDW(4) MDW(5) MDW(6) MDW(7) MDW(8) }
 #undef MDW
             BT_LAUNCH_CHECK();
-            BT_LAUNCH(BTK_SUM_PARTIALS, s, dense_mfma_sum, dim3(bt_div_up((long long)rows * d->in + rows, 256)), dim3(256), 0,
+            BT_LAUNCH(BTK_SUM_PARTIALS, s, dense_mfma_sum, dim3(bt_div_up(16 * d->in + 16, 32), d->buckets), dim3(256), 0,
                       pw, pb, dw, dbias, *d, tab);
             BT_LAUNCH_CHECK();
             return BT_OK;

@@ -219,8 +219,9 @@ struct PermScope {
 // groups_ready: the segment entry lists of this batch are already in ft_ws (bt_net_forward_backward builds them
 // before it forks the side stream); otherwise they are built here, in stream order
 // perm_on_side: the bucket-order permutation is being built on the side stream (ev_perm): joined before the layers
+// n_layers: dense layers to run (the fused tail of bt_net_forward_backward takes over after the first)
 int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bool want_gz0 = false,
-                 bool head_in_ft = false, bool groups_ready = false, bool perm_on_side = false) {
+                 bool head_in_ft = false, bool groups_ready = false, bool perm_on_side = false, int n_layers = -1) {
     bt_ft_desc f = ft_desc(n, b->batch);
     const int32_t *idx[2] = {b->stm, b->nstm};
     const float *w0 = nullptr;
@@ -250,7 +251,8 @@ int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bo
         return rc;
     const float *x = n->hid;
     if (perm_on_side) BT_HIP(hipStreamWaitEvent(s, n->ev_perm, 0));
-    for (int k = 0; k < n->d.n_dense; k++) {
+    if (n_layers < 0) n_layers = n->d.n_dense;
+    for (int k = 0; k < n_layers; k++) {
         bt_dense_desc q = dn_desc(n, k, b->batch);
         if (fuse_loss && k == n->d.n_dense - 1) {
             // final layer + sigmoid-MSE + its gradient in one kernel; the partials are summed by the head backward
@@ -271,7 +273,7 @@ int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bo
             x = n->ap[k];
         }
     }
-    if (has_skip(&n->d)) {  // net output = last layer + skip neurons
+    if (has_skip(&n->d) && n_layers == n->d.n_dense) {  // net output = last layer + skip neurons
         const int L = n->d.n_dense, n_out = n->d.dense_out[L - 1];
         BT_HIP(hipMemcpyAsync(n->yfin, n->a[L - 1], sizeof(float) * b->batch * n_out, hipMemcpyDeviceToDevice, s));
         for (int k = 0; k < L - 1; k++)
@@ -377,6 +379,10 @@ int bt_net_create(const bt_net_desc *desc, int max_batch, float *ext_params, flo
         bt_dense_desc q = dn_desc(n, k, max_batch);
         size_t wsb = bt_dense_backward_workspace_bytes(&q);
         if (wsb == 0) return fail(BT_ERR_INVALID);
+        if (k >= 1 && k + 1 < desc->n_dense) {  // (fused tail partials, if that path is taken)
+            const bt_dense_desc q2 = dn_desc(n, k + 1, max_batch);
+            if (bt_internal_dense_tail_ok(&q, &q2)) wsb = std::max(wsb, bt_internal_dense_tail_workspace_bytes(&q));
+        }
         if (wsb > n->dense_ws_bytes) n->dense_ws_bytes = wsb;
     }
     for (int k = 0; k < desc->n_dense && !n->perm; k++) {
@@ -477,8 +483,21 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
     // HBM-bound in a small-footprint kernel shape, the other LDS-bound, and they share the CUs.
     const bool side_head = fuse_loss && fuse_ft && L == 1;
     const bool head_in_ft = side_head && bt_internal_ft_forward_head_ok(&f, q0.buckets) && b->batch <= 1024 * 64;
-    if (int rc = forward_impl(n, s, b, fuse_loss, side_head, head_in_ft, true, perm.built)) return rc;
-    if (!fuse_loss)
+    // three-layer nets whose two last layers are tiny and bucketed (4_multi_layer.rs): those layers, the loss and
+    // their backward pass run as one kernel per bucket-pure item
+    bt_dense_desc q1 = dn_desc(n, L >= 2 ? L - 2 : 0, b->batch);
+    const bool tail = L == 3 && perm.built && n->d.loss_kind == BT_LOSS_SIGMOID_MSE && !has_skip(&n->d) &&
+                      !has_post(&n->d, 0) && !has_post(&n->d, 1) && n->d.dense_bucketed[1] && n->d.dense_bucketed[2] &&
+                      bt_internal_dense_tail_ok(&q1, &q_last);
+    if (int rc = forward_impl(n, s, b, fuse_loss && !tail, side_head, head_in_ft, true, perm.built, tail ? 1 : -1)) return rc;
+    if (tail) {
+        if (int rc = bt_internal_dense_tail(s, &q1, &q_last, n->params + n->t_off[4], n->params + n->t_off[5],
+                                            n->params + n->t_off[6], n->params + n->t_off[7], n->a[0], b->targets,
+                                            n->d.use_entry_weights ? b->entry_weights : nullptr, n->a[2], n->ga[0],
+                                            n->grads + n->t_off[4], n->grads + n->t_off[5], n->grads + n->t_off[6],
+                                            n->grads + n->t_off[7], loss_sum_dev, n->dense_ws, n->dense_ws_bytes))
+            return rc;
+    } else if (!fuse_loss)
         if (int rc = bt_loss(s, n->d.loss_kind, b->batch, n->d.dense_out[L - 1], net_output(n), b->targets,
                              n->d.use_entry_weights ? b->entry_weights : nullptr, n->d.loss_power, loss_sum_dev,
                              n->grad_y))
@@ -512,7 +531,7 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
         BT_HIP(hipStreamWaitEvent(s, n->ev_head, 0));  // the step's gradients and loss are complete on `s`
         return BT_OK;
     }
-    for (int k = L - 1; k >= 0; k--) {
+    for (int k = tail ? 0 : L - 1; k >= 0; k--) {
         bt_dense_desc q = dn_desc(n, k, b->batch);
         const float *x = (k == 0) ? n->hid : (has_post(&n->d, k - 1) ? n->ap[k - 1] : n->a[k - 1]);
         const float *gy = (k == L - 1) ? n->grad_y : n->ga[k];
