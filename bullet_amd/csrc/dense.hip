@@ -697,7 +697,6 @@ struct DensePermTab {
     int max_items = 0;
 };
 thread_local DensePermTab g_dense_tab;
-#define g_dense_perm (g_dense_tab.perm)
 constexpr int BP_THREADS = 1024;
 constexpr int DX_CH = 64;  // positions per item = 4 waves x one 16-row MFMA tile
 
@@ -1468,7 +1467,7 @@ int dense_mid_launch(hipStream_t s, const bt_dense_desc *d, const float *w, cons
                      const int32_t *bucket, float *dst, bool dx) {
     const size_t lds = (size_t)d->out * (d->in + 4) * sizeof(float);
     dim3 grid(bt_div_up(d->batch, DM_CHUNK)), block(DM_THREADS);
-    const int32_t *perm = d->buckets > 1 ? g_dense_perm : nullptr;
+    const int32_t *perm = d->buckets > 1 ? g_dense_tab.perm : nullptr;
 #define DML(NX)                                                                                                      \
     case NX:                                                                                                         \
         if (dx) {                                                                                                    \
@@ -1501,7 +1500,7 @@ int dense_validate(const bt_dense_desc *d, const char *who) {
 }  // namespace
 
 // ---- internal entry points used by net.hip (declared in common.h)
-// bucket-sorted position order for the mid-size bucketed layers (see g_dense_perm)
+// bucket-sorted position order for the mid-size bucketed layers (see g_dense_tab.perm)
 bool bt_internal_dense_wants_perm(const bt_dense_desc *d) {
     return dense_validate(d, "dense_wants_perm") == BT_OK && d->buckets > 1 && d->buckets <= 16 && !dense_fwd_small_ok(d) &&
            dense_mid_ok(d);
@@ -1726,7 +1725,7 @@ int bt_dense_backward(void *stream, const bt_dense_desc *d, const float *w, cons
             if (grad_x)
                 if (int rc = dense_mid_launch(s, d, w, nullptr, gz, bucket, grad_x, true)) return rc;
             BT_LAUNCH(BTK_DENSE_BWD_DW, s, dense_mid_dw_kernel, dim3(nrm, bt_div_up(d->out, DM_OH)), dim3(DM_THREADS), 0, x,
-                      bucket, gz, pw, pb, *d, d->buckets > 1 ? g_dense_perm : nullptr);
+                      bucket, gz, pw, pb, *d, d->buckets > 1 ? g_dense_tab.perm : nullptr);
             BT_LAUNCH_CHECK();
         }
         BT_LAUNCH(BTK_SUM_PARTIALS, s, sum_partials_t_kernel, dim3(bt_div_up((long long)rows * d->in, 256)), dim3(256), 0, pw,
