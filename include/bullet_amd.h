@@ -116,7 +116,8 @@ typedef struct {
                      LDS-resident kernels are then processed segment by segment through them
                      (bt_ft_forward_prebuilt / bt_ft_backward*). It is a promise about the data: an index
                      outside its entry's segment sets a device flag (bt_ft_segment_violations) and turns that
-                     entry's forward output into NaN instead of being summed. Must divide cols. */
+                     entry's forward output into NaN instead of being summed. Must divide cols; the index lists
+                     must then be 16-byte aligned with nnz a multiple of 4 and <= 32 (else: any-shape kernels). */
 } bt_ft_desc;
 
 /* w: F32[stride*cols] column-major (docs/4-saved-networks.md:21-29); bias: F32[rows] or NULL;
