@@ -139,6 +139,11 @@ NETS = {
     # with six 64-column blocks per wave in the weight-gradient pass
     "l1_in1536_mfma": (dict(num_inputs=768, nnz=32, ft_out=768, ft_act="crelu", num_buckets=8,
                             dense=[(16, "screlu", True), (1, "identity", True)]), ("chess768", None, False), 8, 0),
+    # the dense part of BASELINE configs[2] at its real widths (1024 -> 16 -> 32 -> 1, all bucketed) over a small table:
+    # MFMA first layer with four 64-column blocks per wave + the fused tail, gradients against the oracle
+    "l1_in1024_mfma_tail": (dict(num_inputs=768, nnz=32, ft_out=512, ft_act="screlu", num_buckets=8,
+                                 dense=[(16, "screlu", True), (32, "screlu", True), (1, "identity", True)],
+                                 use_entry_weights=True), ("chess768", None, False), 8, 0),
     "single_perspective": (dict(num_inputs=768, nnz=32, ft_out=64, ft_act="crelu", perspectives=1,
                                 dense=[(8, "relu", False), (1, "identity", False)], use_entry_weights=True),
                            ("chess768", None, False), 1, 0),
