@@ -43,6 +43,12 @@ struct bt_net {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_index = nullptr, ev_fwd = nullptr, ev_head = nullptr, ev_perm = nullptr;
     size_t ft_ws_bytes = 0, dense_ws_bytes = 0;
+    // bt_net_hint_next_batch: the index structures of the NEXT batch (segment entry lists, bucket permutation, sorted
+    // lists) are built on the side stream at the end of the current step, into a second set of buffers
+    void *ft_ws_alt = nullptr, *perm_alt = nullptr;
+    bt_batch next = {}, prep_key = {};
+    bool has_next = false, prepared = false;
+    hipEvent_t next_ready = nullptr, ev_next = nullptr;
 };
 
 namespace {
@@ -208,11 +214,13 @@ int check_batch(const bt_net *net, const bt_batch *b, const char *who) {
 struct PermScope {
     int rc = BT_OK;
     bool built = false;
-    PermScope(bt_net *n, hipStream_t s, const bt_batch *b) {
-        if (!n->perm || !b->buckets || b->batch > 64 * 1024) return;
-        rc = bt_internal_bucket_perm(s, b->buckets, b->batch, n->d.num_buckets, n->perm);
+    // build = false: n->perm already holds this batch's permutation (bt_net_hint_next_batch), install it only
+    PermScope(bt_net *n, hipStream_t s, const bt_batch *b, bool build = true) {
+        if (!perm_usable(n, b)) return;
+        if (build) rc = bt_internal_bucket_perm(s, b->buckets, b->batch, n->d.num_buckets, n->perm);
         if (rc == BT_OK) bt_internal_dense_set_perm(n->perm, b->batch, n->d.num_buckets), built = true;
     }
+    static bool perm_usable(const bt_net *n, const bt_batch *b) { return n->perm && b->buckets && b->batch <= 64 * 1024; }
     ~PermScope() { bt_internal_dense_set_perm(nullptr, 0, 0); }
 };
 
@@ -283,6 +291,26 @@ int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bo
                 BT_LAUNCH_CHECK();
             }
     }
+    return BT_OK;
+}
+
+// end of a step: build the hinted batch's index structures on the side stream into the second buffer set. The side
+// stream is ordered behind ev_fork, i.e. behind everything queued on the compute stream before this step, which
+// includes the last readers of that buffer set (the step before this one).
+int prepare_next(bt_net *n) {
+    if (!n->has_next) return BT_OK;
+    n->has_next = false;
+    const bt_batch *b = &n->next;
+    bt_ft_desc f = ft_desc(n, b->batch);
+    const int32_t *idx[2] = {b->stm, b->nstm};
+    BT_HIP(hipStreamWaitEvent(n->side, n->ev_fork, 0));
+    if (n->next_ready) BT_HIP(hipStreamWaitEvent(n->side, n->next_ready, 0));
+    if (int rc = bt_internal_ft_build_groups(n->side, &f, idx, n->ft_ws_alt, n->ft_ws_bytes)) return rc;
+    if (n->perm_alt && PermScope::perm_usable(n, b))
+        if (int rc = bt_internal_bucket_perm(n->side, b->buckets, b->batch, n->d.num_buckets, n->perm_alt)) return rc;
+    if (int rc = bt_internal_ft_build_sorted(n->side, &f, idx, n->ft_ws_alt, n->ft_ws_bytes)) return rc;
+    BT_HIP(hipEventRecord(n->ev_next, n->side));
+    n->prepared = true, n->prep_key = *b;
     return BT_OK;
 }
 
@@ -400,7 +428,8 @@ int bt_net_create(const bt_net_desc *desc, int max_batch, float *ext_params, flo
         hipEventCreateWithFlags(&n->ev_index, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&n->ev_fwd, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&n->ev_head, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&n->ev_perm, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&n->ev_perm, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&n->ev_next, hipEventDisableTiming) != hipSuccess) {
         bt_set_error("bt_net_create: could not create the side stream / events");
         return fail(BT_ERR_HIP);
     }
@@ -422,6 +451,8 @@ int bt_net_destroy(bt_net *n) {
     if (n->ev_fwd) (void)hipEventDestroy(n->ev_fwd);
     if (n->ev_head) (void)hipEventDestroy(n->ev_head);
     if (n->ev_perm) (void)hipEventDestroy(n->ev_perm);
+    if (n->ev_next) (void)hipEventDestroy(n->ev_next);
+    bt_free(n->ft_ws_alt), bt_free(n->perm_alt);
     if (n->side) (void)hipStreamDestroy(n->side);
     delete n;
     return BT_OK;
@@ -461,16 +492,29 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
     hipStream_t s = bt_stream(stream);
     bt_ft_desc f = ft_desc(n, b->batch);
     const int32_t *idx[2] = {b->stm, b->nstm};
-    // segment-grouped tables: the entry lists are needed by the forward pass too, so they are built on `s` first
-    if (int rc = bt_internal_ft_build_groups(s, &f, idx, n->ft_ws, n->ft_ws_bytes)) return rc;
-    // fork: sorted index build on the side stream, ordered after everything already queued on `s`
-    BT_HIP(hipEventRecord(n->ev_fork, s));
-    BT_HIP(hipStreamWaitEvent(n->side, n->ev_fork, 0));
-    PermScope perm(n, n->side, b);  // (multi-layer bucketed nets) needed after the FT forward: side stream first
+    // Were this batch's index structures built ahead (bt_net_hint_next_batch during the previous step)? Then they are
+    // in the second buffer set: swap the sets and join the side stream once instead of building here.
+    const bool ready = n->prepared && n->prep_key.batch == b->batch && n->prep_key.stm == b->stm &&
+                       n->prep_key.nstm == b->nstm && n->prep_key.buckets == b->buckets;
+    n->prepared = false;
+    if (ready) {
+        std::swap(n->ft_ws, n->ft_ws_alt), std::swap(n->perm, n->perm_alt);
+        BT_HIP(hipEventRecord(n->ev_fork, s));
+        BT_HIP(hipStreamWaitEvent(s, n->ev_next, 0));
+    } else {
+        // segment-grouped tables: the entry lists are needed by the forward pass too, so they are built on `s` first
+        if (int rc = bt_internal_ft_build_groups(s, &f, idx, n->ft_ws, n->ft_ws_bytes)) return rc;
+        // fork: sorted index build on the side stream, ordered after everything already queued on `s`
+        BT_HIP(hipEventRecord(n->ev_fork, s));
+        BT_HIP(hipStreamWaitEvent(n->side, n->ev_fork, 0));
+    }
+    PermScope perm(n, n->side, b, !ready);  // (multi-layer bucketed nets) needed after the FT forward: side stream first
     if (perm.rc) return perm.rc;
-    if (perm.built) BT_HIP(hipEventRecord(n->ev_perm, n->side));
-    if (int rc = bt_internal_ft_build_sorted(n->side, &f, idx, n->ft_ws, n->ft_ws_bytes)) return rc;
-    BT_HIP(hipEventRecord(n->ev_index, n->side));
+    if (!ready) {
+        if (perm.built) BT_HIP(hipEventRecord(n->ev_perm, n->side));
+        if (int rc = bt_internal_ft_build_sorted(n->side, &f, idx, n->ft_ws, n->ft_ws_bytes)) return rc;
+        BT_HIP(hipEventRecord(n->ev_index, n->side));
+    }
     const int L = n->d.n_dense;
     // fusion decisions (shape-dependent, see dense.hip / ft.hip): loss into the final head's forward, the head's dX
     // into the FT backward staging
@@ -489,7 +533,9 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
     const bool tail = L == 3 && perm.built && n->d.loss_kind == BT_LOSS_SIGMOID_MSE && !has_skip(&n->d) &&
                       !has_post(&n->d, 0) && !has_post(&n->d, 1) && n->d.dense_bucketed[1] && n->d.dense_bucketed[2] &&
                       bt_internal_dense_tail_ok(&q1, &q_last);
-    if (int rc = forward_impl(n, s, b, fuse_loss && !tail, side_head, head_in_ft, true, perm.built, tail ? 1 : -1)) return rc;
+    if (int rc = forward_impl(n, s, b, fuse_loss && !tail, side_head, head_in_ft && !ready, true, perm.built && !ready,
+                              tail ? 1 : -1))
+        return rc;
     if (tail) {
         if (int rc = bt_internal_dense_tail(s, &q1, &q_last, n->params + n->t_off[4], n->params + n->t_off[5],
                                             n->params + n->t_off[6], n->params + n->t_off[7], n->a[0], b->targets,
@@ -559,7 +605,7 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
                                               n->dense_ws_bytes))
             return rc;
     }
-    BT_HIP(hipStreamWaitEvent(s, n->ev_index, 0));  // join
+    if (!ready) BT_HIP(hipStreamWaitEvent(s, n->ev_index, 0));  // join
     if (fuse_ft) {
         if (int rc = bt_internal_ft_backward_fused(s, &f, n->gz0, n->params + n->t_off[2],
                                                    n->d.dense_bucketed[0] ? b->buckets : nullptr, q0.buckets, n->hid,
@@ -569,7 +615,22 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
     } else if (int rc = bt_ft_backward_prebuilt(s, &f, n->g_hid, n->hid, n->saved, n->grads + n->t_off[0],
                                                 n->grads + n->t_off[1], n->ft_ws, n->ft_ws_bytes))
         return rc;
-    return factor_reduce();
+    if (int rc = factor_reduce()) return rc;
+    return prepare_next(n);
+}
+
+int bt_net_hint_next_batch(bt_net *n, const bt_batch *next, void *ready_event) {
+    BT_REQUIRE(n, "bt_net_hint_next_batch: null net");
+    n->has_next = false;
+    if (!next) return BT_OK;
+    if (int rc = check_batch(n, next, "bt_net_hint_next_batch")) return rc;
+    if (!n->ft_ws_alt) {  // the second buffer set, on first use
+        if (int rc = bt_malloc(&n->ft_ws_alt, n->ft_ws_bytes)) return rc;
+        if (n->perm)
+            if (int rc = bt_malloc(&n->perm_alt, bt_internal_bucket_perm_bytes(n->max_batch, n->d.num_buckets))) return rc;
+    }
+    n->next = *next, n->next_ready = reinterpret_cast<hipEvent_t>(ready_event), n->has_next = true;
+    return BT_OK;
 }
 
 // save_to_checkpoint, crates/bullet_lib/src/value/save.rs:24-43 (directories are created if missing, errors of the

@@ -534,17 +534,32 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
         return BT_OK;
     };
 
-    for (long long step = 0; step < total_steps; step++) {
-        const int set = (int)(step & 1);
-        const int ring = (int)(step % LOSS_RING);
-        // compute waits for this batch's upload; the learning rate goes through a pinned ring (run.rs:171-173)
-        TRY_HIP(hipStreamWaitEvent(bt_stream(compute_stream), uploaded[set], 0));
-        lr_host[ring] = bt_lr_at(&cfg->lr, batch, sb);
-        TRY(bt_memcpy_h2d_async(lr_dev + ring, lr_host + ring, sizeof(float), compute_stream));
+    auto dev_batch = [&](int set) {
         bt_batch bb;
         bb.batch = B;
         bb.stm = dev[set].stm, bb.nstm = dev[set].nstm, bb.buckets = dev[set].buckets;
         bb.targets = dev[set].targets, bb.entry_weights = dev[set].weights;
+        return bb;
+    };
+    int next_slot = -1;
+    for (long long step = 0; step < total_steps; step++) {
+        const int set = (int)(step & 1);
+        const int ring = (int)(step % LOSS_RING);
+        // next batch: upload into the other device set while this step computes (run.rs:194-207). It is enqueued
+        // BEFORE this step, so that the net can be told about it (its index structures are then built during this
+        // step); the other set was last read by the step before this one (`consumed`).
+        if (step + 1 < total_steps) {
+            TRY(take_ready(&next_slot));
+            if (step >= 1) TRY_HIP(hipStreamWaitEvent(bt_stream(copy_stream), consumed[set ^ 1], 0));
+            TRY(upload(next_slot, set ^ 1));
+            const bt_batch nb = dev_batch(set ^ 1);
+            TRY(bt_net_hint_next_batch(net, &nb, uploaded[set ^ 1]));
+        }
+        // compute waits for this batch's upload; the learning rate goes through a pinned ring (run.rs:171-173)
+        TRY_HIP(hipStreamWaitEvent(bt_stream(compute_stream), uploaded[set], 0));
+        lr_host[ring] = bt_lr_at(&cfg->lr, batch, sb);
+        TRY(bt_memcpy_h2d_async(lr_dev + ring, lr_host + ring, sizeof(float), compute_stream));
+        const bt_batch bb = dev_batch(set);
         TRY(bt_net_forward_backward(net, compute_stream, &bb, loss_dev + ring));
         TRY(bt_net_optimiser_step(net, compute_stream, adj_dev, lr_dev + ring));
         TRY_HIP(hipEventRecord(consumed[set], bt_stream(compute_stream)));
@@ -552,14 +567,9 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
         TRY_HIP(hipEventRecord(loss_ready[ring], bt_stream(compute_stream)));
         pending.push_back({sb, batch});
 
-        // next batch: upload into the other device set while this step computes (run.rs:194-207)
         if (prev_slot >= 0) TRY(release_slot(prev_slot));
         prev_slot = cur_slot;
-        if (step + 1 < total_steps) {
-            TRY(take_ready(&cur_slot));
-            if (step >= 1) TRY_HIP(hipStreamWaitEvent(bt_stream(copy_stream), consumed[set ^ 1], 0));
-            TRY(upload(cur_slot, set ^ 1));
-        }
+        cur_slot = next_slot;
         TRY(deliver(false));
         if (++batch == bps) batch = 0, sb++;
     }

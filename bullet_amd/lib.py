@@ -129,7 +129,7 @@ SYMBOLS = [
     "bt_net_set_optimiser",
     "bt_net_param_count", "bt_net_num_tensors", "bt_net_tensor_size", "bt_net_tensor_offset", "bt_net_create",
     "bt_net_destroy", "bt_net_params", "bt_net_grads", "bt_net_momentum", "bt_net_velocity", "bt_net_set_adamw",
-    "bt_net_forward_backward", "bt_net_optimiser_step", "bt_net_forward",
+    "bt_net_forward_backward", "bt_net_optimiser_step", "bt_net_forward", "bt_net_hint_next_batch",
     "bt_input_init", "bt_input_num_inputs", "bt_input_max_active", "bt_map_batch", "bt_map_batch_device",
     "bt_net_init_weights_host", "bt_lr_at", "bt_wdl_at", "bt_reader_open", "bt_reader_next", "bt_reader_close",
     "bt_train_run",
@@ -207,6 +207,7 @@ def load():
     L.bt_net_destroy.argtypes = [C.c_void_p]
     L.bt_net_set_adamw.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 5
     L.bt_net_forward_backward.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.c_void_p]
+    L.bt_net_hint_next_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p]
     L.bt_net_optimiser_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bt_net_forward.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]
     L.bt_input_init.argtypes = [C.POINTER(InputDesc), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
@@ -414,6 +415,10 @@ class Net:
         import torch
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
         check(self.L.bt_net_forward_backward(self.h, s, C.byref(batch), self.loss.data_ptr()))
+
+    def hint_next(self, batch):
+        """bt_net_hint_next_batch: `batch` (device-resident, complete) is what the step after the coming one uses"""
+        check(self.L.bt_net_hint_next_batch(self.h, C.byref(batch) if batch is not None else None, None))
 
     def optimiser_step(self, adj_dev, lr_dev, stream=None):
         import torch

@@ -289,6 +289,13 @@ typedef struct {
 
 /* fwd + bwd: fills the flat gradient (unscaled batch sums, run.rs:130) and loss_sum_dev[0]. */
 int bt_net_forward_backward(bt_net *net, void *stream, const bt_batch *batch, float *loss_sum_dev);
+/* Optional pipelining hint, given BEFORE bt_net_forward_backward(current): `next` is the batch of the following step
+ * (same net, its tensors complete in `stream` order by now, or once `ready_event` -- a hipEvent_t, may be NULL -- has
+ * fired). Multi-layer / king-bucketed nets then build next's index structures (entry lists, bucket order, sorted
+ * lists: they depend on the indices only) on their side stream while the current step runs, in a second buffer
+ * set, and the following bt_net_forward_backward(next) starts with them in place. Results are identical with or
+ * without the hint; a hint that does not match the following call is ignored. No counterpart in the reference. */
+int bt_net_hint_next_batch(bt_net *net, const bt_batch *next, void *ready_event);
 /* AdamW on every tensor with g = adj * grad (adj = 1/global_batch), adam.rs:121-131 */
 int bt_net_optimiser_step(bt_net *net, void *stream, const float *adj_dev, const float *lr_dev);
 /* Which OptimiserState the step uses: AdamW (default, adam.rs), RAdam (radam.rs) or Ranger = RAdam + lookahead

@@ -259,6 +259,37 @@ def test_full_size_config2_properties():
     net.close()
 
 
+@pytest.mark.parametrize("name", ["cfg3_multilayer_segment", "cfg2_buckets", "l1_in1024_mfma_tail"])
+def test_next_batch_hint_changes_nothing(name):
+    """bt_net_hint_next_batch: index structures of the next batch built ahead on the side stream, second buffer set.
+    Six steps over three alternating batches with correct hints, with a wrong hint and without hints: bit-identical."""
+    cfg, (kind, layout, fact), nb, ft_eff = NETS[name]
+    batches = fixture_batches(kind, layout, fact, nb, 0.75, 3, batch=1400)
+    if cfg.get("use_entry_weights"):
+        batches = [(s, n, b, t, np.full(t.shape[0], 0.75, np.float32)) for s, n, b, t, _ in batches]
+    dev_b = [[gu.dev(a) for a in bt] for bt in batches]
+    runs = []
+    for mode in ("none", "right", "wrong"):
+        net = lib.Net(lib.make_net_desc(**cfg), 1400)
+        net.init_weights(seed=9, ft_effective_inputs=ft_eff)
+        tbs = [net.make_batch(*t) for t in dev_b]
+        adj, lrd = torch.tensor([1.0 / 1400], device="cuda"), torch.tensor([0.001], device="cuda")
+        losses = []
+        for i in range(6):
+            if mode == "right":
+                net.hint_next(tbs[(i + 1) % 3])
+            elif mode == "wrong":
+                net.hint_next(tbs[(i + 2) % 3])
+            net.forward_backward(tbs[i % 3])
+            net.optimiser_step(adj, lrd)
+            torch.cuda.synchronize()
+            losses.append(net.loss.item())
+        runs.append((losses, net.params.clone()))
+        net.close()
+    for losses, params in runs[1:]:
+        assert losses == runs[0][0] and torch.equal(params, runs[0][1])
+
+
 def test_full_size_config3_properties():
     """BASELINE configs[2] at its full size (HalfKA, 16 king buckets, F = 12288 -> 1024x2 pairwise -> 16 -> 32 -> 1,
     8 output buckets, B = 16384, real positions): size-independent checks of the segment-grouped path.

@@ -37,7 +37,10 @@ torch.cuda.synchronize()
 lib.profile_start(4096)
 t0 = time.perf_counter()
 K = 20
+HINT = os.environ.get("BT_NO_HINT", "0") != "1"  # bt_net_hint_next_batch: next step's index built during this one
 for _ in range(K):
+    if HINT:
+        net.hint_next(tb)
     net.forward_backward(tb)
     net.optimiser_step(adj, lr)
 torch.cuda.synchronize()
