@@ -4,7 +4,9 @@
 // (crates/bullet_lib/src/value.rs:77-117), fanned out over worker threads like
 // ModelInputsMapper::map (crates/trainer/src/model/inputs.rs:86-109).  Integer outputs must be bit-exact.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -207,3 +209,96 @@ int bt_map_batch(const bt_input_desc *d, const bt_map_opts *o, const void *recor
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------ text positions
+// `<fen> | <score> | <result>` -> ChessBoard, the FromStr impl of bulletformat 1.8.0 (a crates.io dependency that is
+// not in the reference tree: restated from its published behaviour, **parity unpinned** except for what the
+// reference's own fixture pins -- side-to-move-relative boards, low-nibble-first piece list, ksq = own king,
+// opp_ksq = opponent king ^ 56, result 0/1/2 -- see SURVEY.md Appendix B). Call sites: InMemoryTextLoader
+// (crates/bullet_lib/src/value/loader/text.rs:21-35) and eval (crates/bullet_lib/src/value.rs:217).
+namespace {
+const char *skip_ws(const char *p) {
+    while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n') p++;
+    return p;
+}
+std::string trimmed(const char *a, const char *b) {
+    while (a < b && (*a == ' ' || *a == '\t' || *a == '\r' || *a == '\n')) a++;
+    while (b > a && (b[-1] == ' ' || b[-1] == '\t' || b[-1] == '\r' || b[-1] == '\n')) b--;
+    return std::string(a, b);
+}
+}  // namespace
+
+extern "C" int bt_chessboard_from_str(const char *line, void *record32) {
+    BT_REQUIRE(line && record32, "bt_chessboard_from_str: null argument");
+    const char *bar1 = std::strchr(line, '|');
+    const char *bar2 = bar1 ? std::strchr(bar1 + 1, '|') : nullptr;
+    BT_REQUIRE(bar1 && bar2, "bt_chessboard_from_str: expected `<fen> | <score> | <result>`");
+    const char *bar3 = std::strchr(bar2 + 1, '|');
+    const std::string score_s = trimmed(bar1 + 1, bar2);
+    const std::string res_s = trimmed(bar2 + 1, bar3 ? bar3 : bar2 + 1 + std::strlen(bar2 + 1));
+    // score: i16 in centipawns, white-relative
+    char *end = nullptr;
+    const long score_l = std::strtol(score_s.c_str(), &end, 10);
+    BT_REQUIRE(!score_s.empty() && *end == '\0' && score_l >= -32768 && score_l <= 32767,
+               "bt_chessboard_from_str: bad score `%s`", score_s.c_str());
+    int result2;  // 2 * result, white-relative
+    if (res_s == "1.0" || res_s == "[1.0]" || res_s == "1") result2 = 2;
+    else if (res_s == "0.5" || res_s == "[0.5]" || res_s == "1/2") result2 = 1;
+    else if (res_s == "0.0" || res_s == "[0.0]" || res_s == "0") result2 = 0;
+    else {
+        bt_set_error("bt_chessboard_from_str: bad game result `%s`", res_s.c_str());
+        return BT_ERR_INVALID;
+    }
+    // board field + side to move
+    uint64_t colour_bb[2] = {0, 0}, piece_bb[6] = {0, 0, 0, 0, 0, 0};
+    const char *p = skip_ws(line);
+    int row = 7, col = 0;
+    for (; *p && *p != ' ' && *p != '\t' && p < bar1; p++) {
+        const char ch = *p;
+        if (ch == '/') {
+            row--, col = 0;
+        } else if (ch >= '1' && ch <= '8') {
+            col += ch - '0';
+        } else {
+            static const char names[] = "PNBRQKpnbrqk";
+            const char *f = std::strchr(names, ch);
+            BT_REQUIRE(f && ch != '\0', "bt_chessboard_from_str: bad piece `%c`", ch);
+            BT_REQUIRE(row >= 0 && col >= 0 && col < 8, "bt_chessboard_from_str: board field overflows");
+            const int id = (int)(f - names);
+            const uint64_t bit = 1ull << (8 * row + col);
+            colour_bb[id / 6] |= bit;
+            piece_bb[id % 6] |= bit;
+            col++;
+        }
+    }
+    p = skip_ws(p);
+    const bool black_to_move = (*p == 'b');
+    int score = (int)score_l;
+    if (black_to_move) {  // side-to-move relative: mirror the ranks, swap the colours, negate score and result
+        for (auto &bb : colour_bb) bb = __builtin_bswap64(bb);
+        for (auto &bb : piece_bb) bb = __builtin_bswap64(bb);
+        std::swap(colour_bb[0], colour_bb[1]);
+        score = -score;
+        result2 = 2 - result2;
+    }
+    ChessRecord r;
+    std::memset(&r, 0, sizeof(r));
+    r.occ = colour_bb[0] | colour_bb[1];
+    BT_REQUIRE(__builtin_popcountll(r.occ) <= 32, "bt_chessboard_from_str: more than 32 pieces");
+    int n = 0;
+    for (uint64_t occ = r.occ; occ; occ &= occ - 1, n++) {
+        const uint64_t bit = occ & (0 - occ);
+        int type = 0;
+        while (type < 6 && !(piece_bb[type] & bit)) type++;
+        const uint8_t pc = (uint8_t)(((colour_bb[1] & bit) ? 8 : 0) | type);
+        r.pcs[n / 2] |= (uint8_t)(pc << (4 * (n & 1)));
+    }
+    const uint64_t own_k = colour_bb[0] & piece_bb[5], opp_k = colour_bb[1] & piece_bb[5];
+    BT_REQUIRE(own_k && opp_k, "bt_chessboard_from_str: a king is missing");
+    r.score = (int16_t)score;  // (i16 negation of -32768 wraps in the crate; out of any real range)
+    r.result = (uint8_t)result2;
+    r.ksq = (uint8_t)__builtin_ctzll(own_k);
+    r.opp_ksq = (uint8_t)(__builtin_ctzll(opp_k) ^ 56);
+    std::memcpy(record32, &r, 32);
+    return BT_OK;
+}

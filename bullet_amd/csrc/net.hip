@@ -370,7 +370,7 @@ int bt_net_create(const bt_net_desc *desc, int max_batch, float *ext_params, flo
     }
     if (ext_grads) n->grads = ext_grads;
     else {
-        if ((rc = dmalloc(&n->grads, off))) return fail(rc);
+        if ((rc = dmalloc(&n->grads, off + 4))) return fail(rc);  // + the loss slot of data-parallel steps
         n->own_grads = true;
     }
     if ((rc = dmalloc(&n->mom, off))) return fail(rc);
@@ -460,6 +460,9 @@ int bt_net_destroy(bt_net *n) {
 
 float *bt_net_params(bt_net *n) { return n ? n->params : nullptr; }
 float *bt_net_grads(bt_net *n) { return n ? n->grads : nullptr; }
+size_t bt_net_flat_size(const bt_net *n) { return n ? n->n_params : 0; }
+int bt_net_max_batch(const bt_net *n) { return n ? n->max_batch : 0; }
+int bt_net_grads_owned(const bt_net *n) { return n && n->own_grads; }
 float *bt_net_momentum(bt_net *n) { return n ? n->mom : nullptr; }
 float *bt_net_velocity(bt_net *n) { return n ? n->vel : nullptr; }
 

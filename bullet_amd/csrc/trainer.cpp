@@ -1,6 +1,7 @@
 // Host side of the training loop: weight init, LR / WDL schedules, the looping fixed-size record reader and
 // run::train for one device.  Mirrors crates/trainer/src/{run.rs,reader.rs,reader/fixed_size.rs,
 // model/weights.rs} and crates/bullet_lib/src/trainer/schedule/{lr,wdl}.rs.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -162,6 +163,9 @@ struct bt_reader {
     size_t file_idx = 0;
     FILE *fp = nullptr;
     uint64_t to_skip = 0;
+    // "text:<path>": InMemoryTextLoader (value/loader/text.rs): every line parsed once, then served round and round
+    std::vector<uint8_t> mem;
+    size_t mem_pos = 0;
 };
 
 namespace {
@@ -178,6 +182,45 @@ bool file_records(const std::string &p, uint64_t *n) {
 
 extern "C" int bt_reader_open(const char *const *paths, int n_paths, uint64_t start, bt_reader **out) {
     BT_REQUIRE(paths && n_paths > 0 && out, "bt_reader_open: bad arguments");
+    if (std::strncmp(paths[0], "text:", 5) == 0) {
+        BT_REQUIRE(n_paths == 1, "bt_reader_open: a text loader takes one file");  // InMemoryTextLoader::new(file_path)
+        FILE *f = std::fopen(paths[0] + 5, "r");
+        if (!f) {
+            bt_set_error("File not found: %s", paths[0] + 5);
+            return BT_ERR_IO;
+        }
+        bt_reader *r = new bt_reader();
+        std::string line;
+        int c, rc = BT_OK;
+        size_t lineno = 0;
+        auto flush = [&]() {
+            lineno++;
+            if (!line.empty() && line.back() == '\r') line.pop_back();  // BufRead::lines strips "\r\n"
+            r->mem.resize(r->mem.size() + 32);
+            rc = bt_chessboard_from_str(line.c_str(), r->mem.data() + r->mem.size() - 32);
+            if (rc) {
+                const std::string why = bt_last_error();
+                bt_set_error("%s: line %zu: %s", paths[0] + 5, lineno, why.c_str());  // the reference unwraps (panics)
+            }
+            line.clear();
+        };
+        while (rc == BT_OK && (c = std::fgetc(f)) != EOF) {
+            if (c == '\n') flush();
+            else line.push_back((char)c);
+        }
+        if (rc == BT_OK && !line.empty()) flush();
+        std::fclose(f);
+        if (rc == BT_OK && r->mem.empty()) {
+            bt_set_error("bt_reader_open: no positions in %s", paths[0] + 5);
+            rc = BT_ERR_IO;
+        }
+        if (rc) {
+            delete r;
+            return rc;
+        }
+        *out = r;  // `start` is ignored, as read_chunks(&self, _: usize, ..) does (text.rs:25)
+        return BT_OK;
+    }
     std::vector<std::string> ps;
     std::vector<uint64_t> counts;
     uint64_t epoch = 0;
@@ -216,6 +259,15 @@ extern "C" int bt_reader_next(bt_reader *r, void *dst, int count) {
     BT_REQUIRE(r && dst && count >= 0, "bt_reader_next: bad arguments");
     uint8_t *p = static_cast<uint8_t *>(dst);
     size_t need = (size_t)count;
+    if (!r->mem.empty()) {  // in-memory text positions: the whole set again and again (text.rs:30-34)
+        while (need > 0) {
+            const size_t take = std::min(need, r->mem.size() / 32 - r->mem_pos);
+            std::memcpy(p, r->mem.data() + r->mem_pos * 32, take * 32);
+            p += take * 32, need -= take;
+            r->mem_pos = (r->mem_pos + take) % (r->mem.size() / 32);
+        }
+        return BT_OK;
+    }
     int empty_opens = 0;
     while (need > 0) {
         if (!r->fp) {
@@ -250,6 +302,56 @@ extern "C" int bt_reader_close(bt_reader *r) {
     if (!r) return BT_OK;
     if (r->fp) std::fclose(r->fp);
     delete r;
+    return BT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ loader throughput
+// run::measure_max_cpu_throughput (crates/trainer/src/run.rs:47-73, ValueTrainer::measure_max_cpu_throughput,
+// crates/bullet_lib/src/value.rs:257-272): the reader + threaded host mapper alone, over the whole schedule.
+extern "C" int bt_measure_loader_throughput(const bt_input_desc *input, const bt_train_config *cfg,
+                                            const char *const *paths, int n_paths, double *positions_per_sec) {
+    BT_REQUIRE(input && cfg && paths, "bt_measure_loader_throughput: null argument");
+    BT_REQUIRE(cfg->batch_size > 0 && cfg->batches_per_superbatch > 0 && cfg->start_superbatch >= 1 &&
+                   cfg->end_superbatch >= cfg->start_superbatch,
+               "bt_measure_loader_throughput: invalid TrainingSteps");
+    const int B = cfg->batch_size, nnz = bt_input_max_active(input), bps = cfg->batches_per_superbatch;
+    const size_t tw = cfg->wdl_output ? 3 : 1;
+    bt_reader *reader = nullptr;
+    const uint64_t start_pos = (uint64_t)B * (uint64_t)bps * (uint64_t)(cfg->start_superbatch - 1);
+    if (int rc = bt_reader_open(paths, n_paths, start_pos, &reader)) return rc;
+    std::vector<uint8_t> records((size_t)B * 32);
+    std::vector<int32_t> stm((size_t)B * nnz), nstm((size_t)B * nnz), buckets(B);
+    std::vector<float> targets((size_t)B * tw), weights(B);
+    using clock = std::chrono::steady_clock;
+    auto secs = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const auto t0 = clock::now();
+    auto sb_timer = t0;
+    long long total = 0;
+    if (cfg->log_rate > 0) std::printf("Measuring CPU Throughput\n");
+    for (int sb = cfg->start_superbatch; sb <= cfg->end_superbatch; sb++) {
+        for (int batch = 0; batch < bps; batch++) {
+            bt_map_opts o;
+            o.out_buckets = cfg->out_buckets, o.blend = bt_wdl_at(&cfg->wdl, batch, sb, cfg->end_superbatch);
+            o.eval_scale = cfg->eval_scale, o.use_win_rate_model = cfg->use_win_rate_model;
+            o.wdl_output = cfg->wdl_output, o.threads = cfg->threads;
+            int rc = bt_reader_next(reader, records.data(), B);
+            if (!rc)
+                rc = bt_map_batch(input, &o, records.data(), B, stm.data(), nstm.data(), buckets.data(), targets.data(),
+                                  weights.data());
+            if (rc) {
+                bt_reader_close(reader);
+                return rc;
+            }
+            total += B;
+        }
+        const auto now = clock::now();
+        if (cfg->log_rate > 0)
+            std::printf("superbatch %d | time %.1fs | %.0f pos/sec | total time %.1fs\n", sb, secs(sb_timer, now),
+                        (double)B * bps / secs(sb_timer, now), secs(t0, now));
+        sb_timer = now;
+    }
+    if (positions_per_sec) *positions_per_sec = (double)total / secs(t0, clock::now());
+    bt_reader_close(reader);
     return BT_OK;
 }
 
@@ -289,14 +391,25 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
     BT_REQUIRE(cfg->batch_size > 0 && cfg->batches_per_superbatch > 0 && cfg->start_superbatch >= 1 &&
                    cfg->end_superbatch >= cfg->start_superbatch,
                "bt_train_run: invalid TrainingSteps");
-    const int B = cfg->batch_size, nnz = bt_input_max_active(input);
+    // data parallel (bt_train_config.dp_*): BG = the global batch every rank reads, B = this rank's shard of it
+    const int BG = cfg->batch_size, nnz = bt_input_max_active(input);
+    const int dp_world = cfg->dp_world > 1 ? cfg->dp_world : 1, dp_rank = dp_world > 1 ? cfg->dp_rank : 0;
+    BT_REQUIRE(dp_rank >= 0 && dp_rank < dp_world, "bt_train_run: dp_rank out of range");
+    BT_REQUIRE(dp_world == 1 || cfg->grad_sync, "bt_train_run: data-parallel training needs grad_sync");
+    const int shard_base = BG / dp_world, shard_rem = BG % dp_world;
+    const int lo = dp_rank * shard_base + (dp_rank < shard_rem ? dp_rank : shard_rem);
+    const int B = shard_base + (dp_rank < shard_rem ? 1 : 0);
+    BT_REQUIRE(B > 0, "bt_train_run: batch_size smaller than dp_world");
+    BT_REQUIRE(B <= bt_net_max_batch(net), "bt_train_run: Mismatched sizes! (net max_batch < batch shard)");
+    const bool dp = dp_world > 1;
+    const bool loss_slot = dp && (cfg->dp_loss_slot || bt_net_grads_owned(net));
     const size_t tw = cfg->wdl_output ? 3 : 1;  // targets per position (value.rs:74)
     const int bps = cfg->batches_per_superbatch;
     const long long total_steps = (long long)(cfg->end_superbatch - cfg->start_superbatch + 1) * bps;
 
     // reader.rs:40: skip batch_size * total_batches(start) records (resume)
     bt_reader *reader = nullptr;
-    const uint64_t start_pos = (uint64_t)B * (uint64_t)bps * (uint64_t)(cfg->start_superbatch - 1);
+    const uint64_t start_pos = (uint64_t)BG * (uint64_t)bps * (uint64_t)(cfg->start_superbatch - 1);
     if (int rc = bt_reader_open(paths, n_paths, start_pos, &reader)) return rc;
 
     constexpr int RING = 4;
@@ -307,7 +420,7 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
     constexpr int LOSS_RING = 4;
     hipEvent_t loss_ready[LOSS_RING] = {nullptr};
     float *loss_host = nullptr, *lr_host = nullptr, *loss_dev = nullptr, *lr_dev = nullptr, *adj_dev = nullptr;
-    std::vector<uint8_t> records((size_t)B * 32);
+    std::vector<uint8_t> records((size_t)BG * 32);
     int rc = BT_OK;
     Loader L;
     std::thread loader_thread;
@@ -390,7 +503,7 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
     TRY(bt_malloc((void **)&lr_dev, sizeof(float) * LOSS_RING));
     TRY(bt_malloc((void **)&adj_dev, sizeof(float)));
     {
-        const float adj = 1.0f / (float)B;  // run.rs:130
+        const float adj = 1.0f / (float)BG;  // run.rs:130 (the GLOBAL batch when data parallel)
         TRY(bt_memcpy_h2d_async(adj_dev, &adj, sizeof(float), compute_stream));
         TRY(bt_stream_sync(compute_stream));
     }
@@ -423,14 +536,19 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
             s.blend = o.blend;
             int lrc;
             if (dev_map) {  // raw records straight into the pinned slot; the device maps them after the upload
-                lrc = bt_reader_next(reader, s.records, B);
+                if (dp) {  // every rank walks the same record stream and keeps its shard
+                    lrc = bt_reader_next(reader, records.data(), BG);
+                    if (!lrc) std::memcpy(s.records, records.data() + (size_t)lo * 32, (size_t)B * 32);
+                } else {
+                    lrc = bt_reader_next(reader, s.records, B);
+                }
                 if (!lrc && !o.wdl_output && !(o.blend >= 0.0f && o.blend <= 1.0f)) {
                     bt_set_error("WDL proportion must be in [0, 1]");  // value.rs:114
                     lrc = BT_ERR_INVALID;
                 }
             } else {
-                lrc = bt_reader_next(reader, records.data(), B);
-                if (!lrc) lrc = bt_map_batch(input, &o, records.data(), B, s.stm, s.nstm, s.buckets, s.targets, s.weights);
+                lrc = bt_reader_next(reader, records.data(), BG);
+                if (!lrc) lrc = bt_map_batch(input, &o, records.data() + (size_t)lo * 32, B, s.stm, s.nstm, s.buckets, s.targets, s.weights);
             }
             s.superbatch = sb, s.batch = batch;
             {
@@ -511,10 +629,10 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
             const Pending p = pending.front();
             const long long k = (long long)(p.sb - cfg->start_superbatch) * bps + p.batch;
             BT_HIP(hipEventSynchronize(loss_ready[k % LOSS_RING]));
-            const float error = loss_host[k % LOSS_RING] / (float)B;  // run.rs:221
+            const float error = loss_host[k % LOSS_RING] / (float)BG;  // run.rs:221
             pending.pop_front();
             running_loss += error;
-            sb_positions += B;
+            sb_positions += BG;
             if (on_batch) on_batch(user, p.sb, p.batch, error);
             if (cfg->log_rate > 0 && p.batch % cfg->log_rate == 0 && p.batch > 0) {
                 const float t = secs(sb_timer, clock::now());
@@ -560,10 +678,24 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
         lr_host[ring] = bt_lr_at(&cfg->lr, batch, sb);
         TRY(bt_memcpy_h2d_async(lr_dev + ring, lr_host + ring, sizeof(float), compute_stream));
         const bt_batch bb = dev_batch(set);
-        TRY(bt_net_forward_backward(net, compute_stream, &bb, loss_dev + ring));
+        // data parallel: the loss sum sits right behind the flat gradient when there is room, so the exchange of a
+        // step is one collective over n + 1 floats
+        float *loss_at = loss_slot ? bt_net_grads(net) + bt_net_flat_size(net) : loss_dev + ring;
+        TRY(bt_net_forward_backward(net, compute_stream, &bb, loss_at));
+        if (dp) {
+            auto sync = [&](float *buf, size_t n) -> int {
+                if (cfg->grad_sync(cfg->grad_sync_user, buf, n, compute_stream)) {
+                    bt_set_error("bt_train_run: grad_sync failed");
+                    return BT_ERR_STATE;
+                }
+                return BT_OK;
+            };
+            TRY(sync(bt_net_grads(net), bt_net_flat_size(net) + (loss_slot ? 1 : 0)));
+            if (!loss_slot) TRY(sync(loss_at, 1));
+        }
         TRY(bt_net_optimiser_step(net, compute_stream, adj_dev, lr_dev + ring));
         TRY_HIP(hipEventRecord(consumed[set], bt_stream(compute_stream)));
-        TRY(bt_memcpy_d2h_async(loss_host + ring, loss_dev + ring, sizeof(float), compute_stream));
+        TRY(bt_memcpy_d2h_async(loss_host + ring, loss_at, sizeof(float), compute_stream));
         TRY_HIP(hipEventRecord(loss_ready[ring], bt_stream(compute_stream)));
         pending.push_back({sb, batch});
 

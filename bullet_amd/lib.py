@@ -101,10 +101,13 @@ class TrainConfig(C.Structure):
     _fields_ = [("batch_size", C.c_int), ("batches_per_superbatch", C.c_int), ("start_superbatch", C.c_int),
                 ("end_superbatch", C.c_int), ("lr", LrSched), ("wdl", WdlSched), ("eval_scale", C.c_float),
                 ("out_buckets", C.c_int), ("use_win_rate_model", C.c_int), ("threads", C.c_int),
-                ("log_rate", C.c_int), ("wdl_output", C.c_int), ("device_mapper", C.c_int)]
+                ("log_rate", C.c_int), ("wdl_output", C.c_int), ("device_mapper", C.c_int),
+                ("dp_rank", C.c_int), ("dp_world", C.c_int), ("grad_sync", C.c_void_p),
+                ("grad_sync_user", C.c_void_p), ("dp_loss_slot", C.c_int)]
 
 
 BATCH_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_float)
+GRAD_SYNC_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 SUPERBATCH_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_float, C.c_float)
 LR = {"constant": 0, "drop": 1, "step": 2, "linear": 3, "cosine": 4, "exp": 5}
 WDL = {"constant": 0, "linear": 1}
@@ -129,6 +132,7 @@ SYMBOLS = [
     "bt_net_set_optimiser",
     "bt_net_param_count", "bt_net_num_tensors", "bt_net_tensor_size", "bt_net_tensor_offset", "bt_net_create",
     "bt_net_destroy", "bt_net_params", "bt_net_grads", "bt_net_momentum", "bt_net_velocity", "bt_net_set_adamw",
+    "bt_net_flat_size", "bt_net_max_batch", "bt_net_grads_owned", "bt_chessboard_from_str", "bt_measure_loader_throughput",
     "bt_net_forward_backward", "bt_net_optimiser_step", "bt_net_forward", "bt_net_hint_next_batch",
     "bt_input_init", "bt_input_num_inputs", "bt_input_max_active", "bt_map_batch", "bt_map_batch_device",
     "bt_net_init_weights_host", "bt_lr_at", "bt_wdl_at", "bt_reader_open", "bt_reader_next", "bt_reader_close",
@@ -154,12 +158,14 @@ def load():
     L.bt_profile_set_filter.argtypes = [C.c_ulonglong]
     L.bt_profile_stop.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int]
     for f in ("bt_ft_backward_workspace_bytes", "bt_dense_backward_workspace_bytes", "bt_net_param_count",
-              "bt_net_tensor_size", "bt_net_tensor_offset"):
+              "bt_net_tensor_size", "bt_net_tensor_offset", "bt_net_flat_size"):
         getattr(L, f).restype = C.c_size_t
     for f in ("bt_net_params", "bt_net_grads", "bt_net_momentum", "bt_net_velocity"):
         getattr(L, f).restype = C.c_void_p
         getattr(L, f).argtypes = [C.c_void_p]
     L.bt_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    L.bt_chessboard_from_str.argtypes = [C.c_char_p, C.c_void_p]
+    L.bt_measure_loader_throughput.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
     L.bt_free.argtypes = [C.c_void_p]
     L.bt_host_alloc_pinned.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     L.bt_host_free_pinned.argtypes = [C.c_void_p]
@@ -359,12 +365,36 @@ class Net:
 
     def train(self, input_desc, paths, batch_size, batches_per_superbatch, end_superbatch, lr, wdl, eval_scale=400.0,
               start_superbatch=1, out_buckets=1, threads=4, log_rate=0, win_rate_model=False, on_batch=None,
-              on_superbatch=None, wdl_output=False, device_mapper=False):
-        """run::train through the C ABI. lr / wdl: LrSched / WdlSched. Returns [(superbatch, running_loss, pos/s)]."""
+              on_superbatch=None, wdl_output=False, device_mapper=False, dist=None):
+        """run::train through the C ABI. lr / wdl: LrSched / WdlSched. Returns [(superbatch, running_loss, pos/s)].
+        dist: an initialised torch.distributed module -> data-parallel training (bt_train_config.dp_*): `batch_size`
+        is the global batch, this rank trains on its shard, and the step buffer (flat gradient + loss sum) is
+        all-reduced once per step on the training loop's compute stream (RCCL when the backend is "nccl")."""
         import torch
         torch.cuda.synchronize()
         cfg = TrainConfig(batch_size, batches_per_superbatch, start_superbatch, end_superbatch, lr, wdl, eval_scale,
                           out_buckets, int(win_rate_model), threads, log_rate, int(wdl_output), int(device_mapper))
+        sync_cb, sync_err = None, []
+        if dist is not None and dist.get_world_size() > 1:
+            def grad_sync(_u, buf, n, stream):
+                try:
+                    if buf != self._gbuf.data_ptr() or n > self._gbuf.numel():
+                        # (only the loss when the caller's buffer has no slot for it: never the case for Net)
+                        raise RuntimeError("grad_sync: not the step buffer of this net")
+                    with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+                        if dist.get_backend() == "gloo":  # CPU collective (tests): staged through the host
+                            host = self._gbuf[:n].cpu()
+                            dist.all_reduce(host)
+                            self._gbuf[:n].copy_(host)
+                        else:
+                            dist.all_reduce(self._gbuf[:n])
+                    return 0
+                except Exception as e:  # an exception must not unwind through the C frames
+                    sync_err.append(e)
+                    return 1
+            sync_cb = GRAD_SYNC_CB(grad_sync)
+            cfg.dp_rank, cfg.dp_world, cfg.dp_loss_slot = dist.get_rank(), dist.get_world_size(), 1
+            cfg.grad_sync = C.cast(sync_cb, C.c_void_p)
         report = []
 
         def sb_cb(_u, sb, loss, pps):
@@ -377,9 +407,39 @@ class Net:
                 on_batch(sb, b, loss)
 
         cpaths = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
-        check(self.L.bt_train_run(self.h, C.byref(input_desc), C.byref(cfg), cpaths, len(paths), BATCH_CB(b_cb),
-                                  SUPERBATCH_CB(sb_cb), None))
+        rc = self.L.bt_train_run(self.h, C.byref(input_desc), C.byref(cfg), cpaths, len(paths), BATCH_CB(b_cb),
+                                 SUPERBATCH_CB(sb_cb), None)
+        if sync_err:
+            raise sync_err[0]
+        check(rc)
         return report
+
+    def eval_raw_output(self, fen, input_desc, out_buckets=1, wdl_output=False):
+        """ValueTrainer::eval_raw_output (value.rs:213-235): "{fen} | 0 | 0.0" -> ChessBoard -> mapper -> forward of a
+        batch of one through bt_net_forward (ModelEvaluator)."""
+        import numpy as np
+        import torch
+        rec = np.zeros(32, dtype=np.uint8)
+        check(self.L.bt_chessboard_from_str(f"{fen} | 0 | 0.0".encode(), rec.ctypes.data))
+        stm, ntm, bk, tg, w = map_batch(input_desc, rec, out_buckets=out_buckets, blend=1.0, wdl=wdl_output, threads=1)
+        t = [torch.from_numpy(a).cuda() for a in (stm, ntm, bk, tg, w)]
+        width = self.desc.dense_out[self.desc.n_dense - 1]
+        out = torch.zeros(width, dtype=torch.float32, device="cuda")
+        loss = torch.zeros(1, dtype=torch.float32, device="cuda")
+        check(self.L.bt_net_forward(self.h, torch.cuda.current_stream().cuda_stream, C.byref(self.make_batch(*t)),
+                                    out.data_ptr(), loss.data_ptr()))
+        return out.cpu().numpy()
+
+    def eval(self, fen, input_desc, out_buckets=1, wdl_output=False):
+        """ValueTrainer::eval (value.rs:237-255): the raw score, or the expected result of a W/D/L head"""
+        import numpy as np
+        vals = self.eval_raw_output(fen, input_desc, out_buckets, wdl_output)
+        if vals.size == 3:
+            e = np.exp(vals - vals.max())  # [loss, draw, win]
+            return float((e[2] + e[1] / np.float32(2.0)) / e.sum())
+        if vals.size == 1:
+            return float(vals[0])
+        raise BtError("Invalid output size!")
 
     def set_params(self, arrays):
         import torch

@@ -276,6 +276,11 @@ float *bt_net_params(bt_net *net);
 float *bt_net_grads(bt_net *net);
 float *bt_net_momentum(bt_net *net);
 float *bt_net_velocity(bt_net *net);
+/* floats in each flat buffer (= bt_net_param_count of its descriptor); the max_batch it was created for; whether
+ * the gradient buffer is library-owned (it then has a spare float behind it, see bt_train_config.dp_loss_slot) */
+size_t bt_net_flat_size(const bt_net *net);
+int bt_net_max_batch(const bt_net *net);
+int bt_net_grads_owned(const bt_net *net);
 /* per-tensor AdamW overrides = Optimiser::set_params_for_weight, optimiser.rs:204-206 */
 int bt_net_set_adamw(bt_net *net, int tensor, float decay, float beta1, float beta2, float min_w, float max_w);
 
@@ -346,6 +351,11 @@ int bt_map_batch(const bt_input_desc *d, const bt_map_opts *o, const void *recor
  * one wave per record, enqueued on `stream` (o->threads is ignored). Indices, terminators and buckets are
  * bit-identical to bt_map_batch; score targets may differ by 1 ulp where the two exp implementations round
  * differently. Only 32 B per position cross PCIe instead of 268 B, and no host thread touches the features. */
+/* `<fen> | <score> | <result>` -> one 32-byte ChessBoard record (host): `ChessBoard::from_str` of bulletformat 1.8.0,
+ * used by InMemoryTextLoader (value/loader/text.rs:28) and ValueTrainer::eval ("{fen} | 0 | 0.0", value.rs:217).
+ * score: centipawns (i16), result 1.0 / 0.5 / 0.0 (also "[1.0]", "1", "1/2", "0" ...), both white-relative in the
+ * text and side-to-move-relative in the record. */
+int bt_chessboard_from_str(const char *line, void *record32);
 int bt_map_batch_device(void *stream, const bt_input_desc *d, const bt_map_opts *o, const void *records_dev, int count,
                         int32_t *stm, int32_t *nstm, int32_t *buckets, float *targets, float *weights);
 
@@ -386,6 +396,9 @@ float bt_wdl_at(const bt_wdl_sched *s, int batch, int superbatch, int final_supe
  * (fixed_size.rs:42-107). bt_reader_next always delivers exactly `count` records (ReadMapLoader's
  * re-chunking with carry-over, reader.rs:31-81). */
 typedef struct bt_reader bt_reader;
+/* A single path of the form "text:<file>" selects InMemoryTextLoader instead (value/loader/text.rs:21-35): one
+ * `<fen> | <score> | <result>` position per line, all parsed up front with bt_chessboard_from_str and then served
+ * round and round; start_position is ignored there, as in the reference. */
 int bt_reader_open(const char *const *paths, int n_paths, uint64_t start_position, bt_reader **reader);
 int bt_reader_next(bt_reader *reader, void *dst_records, int count);
 int bt_reader_close(bt_reader *reader);
@@ -406,7 +419,26 @@ typedef struct {
                                 with loss_kind = BT_LOSS_SOFTMAX_CE and 3 outputs */
     int device_mapper;       /* 1: the loader thread only reads records; they are uploaded raw and mapped by
                                 bt_map_batch_device on the copy stream (`threads` is then unused) */
+    /* Data-parallel training (no counterpart in the reference, which is single-device: SURVEY.md 8e). One process
+     * per GPU calls bt_train_run with the same files and schedule; dp_world <= 1 = off. `batch_size` stays the GLOBAL
+     * batch: every rank reads the same record stream, keeps positions [lo, hi) of each global batch (contiguous
+     * shards, sizes differ by at most one, rank order), runs fwd+bwd on them, then calls `grad_sync` to SUM the
+     * unscaled gradient and the loss over ranks, and steps the optimiser with adj = 1/batch_size, so the replicas
+     * stay bit-identical. `net` needs max_batch >= the shard size. */
+    int dp_rank, dp_world;
+    /* Sums `n_floats` floats at `buf_dev` over all ranks, in place, ordered after the work already enqueued on
+     * `stream` and before anything enqueued on it afterwards (e.g. an RCCL all-reduce). Returns 0 on success.
+     * dp_loss_slot = 1 promises that the gradient buffer of `net` has room for one more float behind its
+     * bt_net_param_count() floats (true for a library-owned buffer): the loss sum is then kept there and a step is ONE
+     * call over n + 1 floats; otherwise the loss is summed by a second call over 1 float. */
+    int (*grad_sync)(void *user, float *buf_dev, size_t n_floats, void *stream);
+    void *grad_sync_user;
+    int dp_loss_slot;
 } bt_train_config;
+/* run::measure_max_cpu_throughput (run.rs:47-73): reader + host mapper alone over the schedule of `cfg` (no device
+ * work); reports per superbatch when cfg->log_rate > 0 and returns the overall positions per second. */
+int bt_measure_loader_throughput(const bt_input_desc *input, const bt_train_config *cfg, const char *const *paths,
+                                 int n_paths, double *positions_per_sec);
 typedef void (*bt_batch_callback)(void *user, int superbatch, int batch, float loss);
 typedef void (*bt_superbatch_callback)(void *user, int superbatch, float running_loss, float positions_per_sec);
 int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_train_config *cfg, const char *const *paths,

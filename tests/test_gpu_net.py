@@ -568,3 +568,34 @@ def test_radam_and_ranger_steps_vs_oracle(kind):
     for t, (a, b) in enumerate(zip(net.get_tensors(net.params), params)):
         gu.assert_close(a, b, rtol=1e-4, atol=2e-5, what=f"{kind}: tensor {t} after 8 steps")
     net.close()
+
+
+@pytest.mark.parametrize("wdl", [False, True])
+def test_eval_fen_matches_oracle_forward(wdl):
+    """ValueTrainer::eval (value.rs:213-255): FEN text -> ChessBoard -> mapper -> forward-only pass of a batch of
+    one, against the oracle's forward on the same mapped position (black to move: the board is flipped)."""
+    cfg = dict(num_inputs=768, nnz=32, ft_out=64, ft_act="screlu", num_buckets=1 if wdl else 8,
+               dense=[(3 if wdl else 1, "identity", not wdl)], **(dict(loss="softmax_ce") if wdl else {}))
+    idesc = lib.make_input_desc("chess768")
+    net = lib.Net(lib.make_net_desc(**cfg), 4)
+    net.init_weights(seed=3)
+    do = ob.make_net(**cfg)
+    params = net.get_tensors(net.params)
+    nb = 1 if wdl else 8
+    for fen in ("rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1",
+                "r1bq1rk1/pp2bppp/2n1pn2/3p4/2PP4/2N1PN2/PP2BPPP/R1BQ1RK1 b - - 4 9", "8/5k2/8/3K4/8/8/4R3/8 b - - 0 60"):
+        rec = np.zeros(32, dtype=np.uint8)
+        lib.check(L.bt_chessboard_from_str(f"{fen} | 0 | 0.0".encode(), rec.ctypes.data))
+        stm, ntm, bk, tg, w = lib.map_batch(idesc, rec, out_buckets=nb, blend=1.0, wdl=wdl, threads=1)
+        ref = np.zeros(3 if wdl else 1, dtype=np.float32)
+        ob.lib().orc_net_forward(C.byref(do), 1, ob.ptr_array(params), ob.ip(stm), ob.ip(ntm), ob.ip(bk), ob.fp(tg),
+                                 ob.fp(w), ob.fp(ref))
+        raw = net.eval_raw_output(fen, idesc, out_buckets=nb, wdl_output=wdl)
+        assert np.allclose(raw, ref, rtol=1e-5, atol=2e-6)
+        val = net.eval(fen, idesc, out_buckets=nb, wdl_output=wdl)
+        if wdl:
+            e = np.exp(ref.astype(np.float64) - ref.max())
+            assert abs(val - (e[2] + e[1] / 2) / e.sum()) < 1e-5 and 0.0 < val < 1.0
+        else:
+            assert abs(val - float(ref[0])) <= 1e-5 * abs(float(ref[0])) + 2e-6
+    net.close()

@@ -88,3 +88,95 @@ def test_reader_loops_files_and_honours_start(tmp_path):
     h = C.c_void_p()
     bad = (C.c_char_p * 1)(b"/nonexistent/file.bf")
     assert L.bt_reader_open(bad, 1, 0, C.byref(h)) == 4 and b"File not found" in L.bt_last_error()
+
+
+# ------------------------------------------------------------------------------------------ text positions
+def _fen_of(record, as_black):
+    """Renders a fixture record (side-to-move relative) as `<fen> | score | result` text, either with white to move
+    (the record as it stands) or as the same position seen with black to move (ranks mirrored, colours swapped,
+    score and result negated) -- parsing either must give the record back."""
+    occ = int(record[:8].copy().view(np.uint64)[0])
+    board, n = {}, 0
+    for sq in range(64):
+        if occ >> sq & 1:
+            pc = (int(record[8 + n // 2]) >> (4 * (n & 1))) & 15
+            n += 1
+            colour, kind = pc >> 3, pc & 7
+            if as_black:
+                board[sq ^ 56] = "pnbrqk"[kind] if colour == 0 else "PNBRQK"[kind]
+            else:
+                board[sq] = "PNBRQK"[kind] if colour == 0 else "pnbrqk"[kind]
+    rows = []
+    for rank in range(7, -1, -1):
+        row, gap = "", 0
+        for file in range(8):
+            ch = board.get(8 * rank + file)
+            if ch is None:
+                gap += 1
+            else:
+                row += (str(gap) if gap else "") + ch
+                gap = 0
+        rows.append(row + (str(gap) if gap else ""))
+    score = int(record[24:26].copy().view(np.int16)[0])
+    res = int(record[26])
+    if as_black:
+        score, res = -score, 2 - res
+    return "%s %s - - 0 1 | %d | %s" % ("/".join(rows), "b" if as_black else "w", score, ["0.0", "0.5", "1.0"][res])
+
+
+def test_chessboard_from_str_round_trips_the_reference_fixture():
+    """bulletformat's FromStr is not in the reference tree (parity unpinned, see the C source); what IS pinned is the
+    record layout of examples/tests/batch.bf, so: every fixture record, written out as text from either side's
+    point of view, must parse back to the identical 32 bytes."""
+    rec = np.fromfile(GOLDEN, dtype=np.uint8).reshape(-1, 32)
+    out = np.zeros(32, dtype=np.uint8)
+    for i in range(0, rec.shape[0], 7):
+        for as_black in (False, True):
+            lib.check(L.bt_chessboard_from_str(_fen_of(rec[i], as_black).encode(), out.ctypes.data))
+            assert np.array_equal(out, rec[i]), (i, as_black)
+
+
+def test_chessboard_from_str_known_position_and_errors():
+    out = np.zeros(32, dtype=np.uint8)
+    lib.check(L.bt_chessboard_from_str(b"rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1 | 37 | [0.5]",
+                                       out.ctypes.data))
+    assert int(out[:8].copy().view(np.uint64)[0]) == 0xFFFF00000000FFFF
+    assert list(out[8:12]) == [0x13, 0x42, 0x25, 0x31]           # R N B Q K B N R, low nibble first
+    assert list(out[12:16]) == [0x00] * 4 and list(out[16:20]) == [0x88] * 4
+    assert list(out[20:24]) == [0x9B, 0xCA, 0xAD, 0xB9]
+    assert int(out[24:26].copy().view(np.int16)[0]) == 37 and out[26] == 1 and out[27] == 4 and out[28] == 60 ^ 56
+    # black to move: score and result flip, the board is seen from black's side (same bytes for the start position)
+    white = out.copy()
+    lib.check(L.bt_chessboard_from_str(b"rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR b KQkq - 0 1 | -37 | 0.5",
+                                       out.ctypes.data))
+    assert np.array_equal(out, white)
+    for bad in (b"8/8/8/8/8/8/8/8 w - - 0 1 | 0 | 0.5", b"k7/8/8/8/8/8/8/K7 w - - 0 1 | 0", b"k7/8/8/8/8/8/8/K7 w | x | 1.0",
+                b"k7/8/8/8/8/8/8/K7 w | 0 | 0.7"):
+        assert L.bt_chessboard_from_str(bad, out.ctypes.data) == 1 and L.bt_last_error()
+
+
+def test_text_reader_serves_the_lines_round_and_round(tmp_path):
+    rec = np.fromfile(GOLDEN, dtype=np.uint8).reshape(-1, 32)[:53]
+    path = tmp_path / "positions.txt"
+    path.write_text("".join(_fen_of(r, i % 2 == 1) + ("\r\n" if i % 3 == 0 else "\n") for i, r in enumerate(rec)))
+    h = C.c_void_p()
+    paths = (C.c_char_p * 1)(b"text:" + str(path).encode())
+    lib.check(L.bt_reader_open(paths, 1, 1000, C.byref(h)))  # start is ignored by the text loader (text.rs:25)
+    out = np.zeros((130, 32), dtype=np.uint8)
+    lib.check(L.bt_reader_next(h, out.ctypes.data, 130))
+    assert np.array_equal(out, rec[np.arange(130) % 53])
+    lib.check(L.bt_reader_next(h, out.ctypes.data, 10))
+    assert np.array_equal(out[:10], rec[(130 + np.arange(10)) % 53])
+    L.bt_reader_close(h)
+    path.write_text("not a position\n")
+    assert L.bt_reader_open(paths, 1, 0, C.byref(h)) != 0 and b"line 1" in L.bt_last_error()
+
+
+def test_loader_throughput_runs_the_schedule_without_a_device():
+    cfg = lib.TrainConfig(4096, 3, 1, 2, lib.LrSched(lib.LR["constant"], 0.001, 0, 0, 0),
+                          lib.WdlSched(lib.WDL["constant"], 0.5, 0, 0), 400.0, 8, 0, 2, 0, 0, 0)
+    idesc = lib.make_input_desc("chess768")
+    pps = C.c_double(0)
+    paths = (C.c_char_p * 1)(GOLDEN.encode())
+    lib.check(L.bt_measure_loader_throughput(C.byref(idesc), C.byref(cfg), paths, 1, C.byref(pps)))
+    assert pps.value > 1e4
