@@ -405,7 +405,11 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
     const bool loss_slot = dp && (cfg->dp_loss_slot || bt_net_grads_owned(net));
     const size_t tw = cfg->wdl_output ? 3 : 1;  // targets per position (value.rs:74)
     const int bps = cfg->batches_per_superbatch;
-    const long long total_steps = (long long)(cfg->end_superbatch - cfg->start_superbatch + 1) * bps;
+    BT_REQUIRE(cfg->stop_superbatch <= 0 ||
+                   (cfg->stop_superbatch >= cfg->start_superbatch && cfg->stop_superbatch <= cfg->end_superbatch),
+               "bt_train_run: stop_superbatch outside [start_superbatch, end_superbatch]");
+    const int last_superbatch = cfg->stop_superbatch > 0 ? cfg->stop_superbatch : cfg->end_superbatch;
+    const long long total_steps = (long long)(last_superbatch - cfg->start_superbatch + 1) * bps;
 
     // reader.rs:40: skip batch_size * total_batches(start) records (resume)
     bt_reader *reader = nullptr;

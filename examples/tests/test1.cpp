@@ -1,0 +1,48 @@
+// examples/tests/test1.rs of the reference in C++: 768 -> 32x2 -> 1 SCReLU, 10 superbatches of one batch of 16384
+// positions from examples/tests/batch.bf (here tests/golden/batch.bf), ConstantLR 1e-3, ConstantWDL 0.2.
+// The reference prints "Expected loss: 0.056420" (test1.rs:54); this program prints the loss it reached and exits
+// non-zero when the six digits differ.
+#include "bullet_amd.hpp"
+
+using namespace bullet_lib;
+
+int main(int argc, char **argv) {
+    const char *data = argc > 1 ? argv[1] : "tests/golden/batch.bf";
+    const std::string out_dir = argc > 2 ? argv[2] : "checkpoints";
+    try {
+        auto trainer = ValueTrainerBuilder()
+                           .dual_perspective()
+                           .optimiser(optimiser::AdamW{})
+                           .inputs(inputs::Chess768{})
+                           .save_format({
+                               SavedFormat::id("l0w").round().quantise<int16_t>(255),
+                               SavedFormat::id("l0b").round().quantise<int16_t>(255),
+                               SavedFormat::id("l1w").round().quantise<int16_t>(64),
+                               SavedFormat::id("l1b").round().quantise<int16_t>(255 * 64),
+                           })
+                           .loss_fn([](auto output, auto target) { return output.sigmoid().squared_error(target); })
+                           .build([](ModelBuilder &builder, Node stm_inputs, Node ntm_inputs) {
+                               auto l0 = builder.new_affine("l0", 768, 32);
+                               auto l1 = builder.new_affine("l1", 64, 1);
+                               auto stm_hidden = l0.forward(stm_inputs).screlu();
+                               auto ntm_hidden = l0.forward(ntm_inputs).screlu();
+                               return l1.forward(stm_hidden.concat(ntm_hidden));
+                           });
+        TrainingSchedule<lr::ConstantLR, wdl::ConstantWDL> schedule{
+            "test1", 400.0f, TrainingSteps{16384, 1, 1, 10}, wdl::ConstantWDL{0.2f}, lr::ConstantLR{0.001f}, 10};
+        LocalSettings settings{4, nullptr, out_dir, 512};
+        loader::DirectSequentialDataLoader data_loader({data});
+        const float before = 400.0f * trainer->eval("rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1");
+        std::printf("Eval: %.3fcp\n", before);
+        trainer->run(schedule, settings, data_loader);
+        std::printf("Expected loss: 0.056420\n");
+        std::printf("Final loss: %.6f\n", trainer->last_superbatch_loss());
+        std::printf("Eval: %.3fcp\n", 400.0f * trainer->eval("rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1"));
+        char got[32];
+        std::snprintf(got, sizeof(got), "%.6f", trainer->last_superbatch_loss());
+        return std::string(got) == "0.056420" ? 0 : 2;
+    } catch (const Error &e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+}

@@ -434,6 +434,10 @@ typedef struct {
     int (*grad_sync)(void *user, float *buf_dev, size_t n_floats, void *stream);
     void *grad_sync_user;
     int dp_loss_slot;
+    /* > 0: leave the loop after this superbatch (start_superbatch <= stop_superbatch <= end_superbatch) while the
+     * schedules keep seeing end_superbatch as the end of training -- how a caller checkpoints between superbatches
+     * (value.rs:197-208): run to the checkpoint, save, call again with start_superbatch = stop_superbatch + 1. */
+    int stop_superbatch;
 } bt_train_config;
 /* run::measure_max_cpu_throughput (run.rs:47-73): reader + host mapper alone over the schedule of `cfg` (no device
  * work); reports per superbatch when cfg->log_rate > 0 and returns the overall positions per second. */
