@@ -166,6 +166,8 @@ struct bt_reader {
     // "text:<path>": InMemoryTextLoader (value/loader/text.rs): every line parsed once, then served round and round
     std::vector<uint8_t> mem;
     size_t mem_pos = 0;
+    // set: `mem` is refilled from a decoding source when it runs out (viribinpack shuffle buffers) instead of wrapping
+    std::function<int(std::vector<uint8_t> &)> refill;
 };
 
 namespace {
@@ -259,6 +261,22 @@ extern "C" int bt_reader_next(bt_reader *r, void *dst, int count) {
     BT_REQUIRE(r && dst && count >= 0, "bt_reader_next: bad arguments");
     uint8_t *p = static_cast<uint8_t *>(dst);
     size_t need = (size_t)count;
+    if (r->refill) {  // one shuffle buffer after the other (viribinpack.rs:143-148)
+        while (need > 0) {
+            if (r->mem_pos * 32 >= r->mem.size()) {
+                if (int rc = r->refill(r->mem)) return rc;
+                r->mem_pos = 0;
+                if (r->mem.empty()) {
+                    bt_set_error("bt_reader_next: the source delivered no positions");
+                    return BT_ERR_IO;
+                }
+            }
+            const size_t take = std::min(need, r->mem.size() / 32 - r->mem_pos);
+            std::memcpy(p, r->mem.data() + r->mem_pos * 32, take * 32);
+            p += take * 32, need -= take, r->mem_pos += take;
+        }
+        return BT_OK;
+    }
     if (!r->mem.empty()) {  // in-memory text positions: the whole set again and again (text.rs:30-34)
         while (need > 0) {
             const size_t take = std::min(need, r->mem.size() / 32 - r->mem_pos);
@@ -295,6 +313,18 @@ extern "C" int bt_reader_next(bt_reader *r, void *dst, int count) {
             }
         }
     }
+    return BT_OK;
+}
+
+extern "C" int bt_reader_open_viribinpack(const char *const *paths, int n_paths, size_t buffer_size_mb, int threads,
+                                          bt_viri_filter filter, void *user, uint64_t shuffle_seed, bt_reader **out) {
+    BT_REQUIRE(out, "bt_reader_open_viribinpack: bad arguments");
+    bt_reader *r = new bt_reader();
+    if (int rc = bt_internal_viri_source(paths, n_paths, buffer_size_mb, threads, filter, user, shuffle_seed, &r->refill)) {
+        delete r;
+        return rc;
+    }
+    *out = r;
     return BT_OK;
 }
 
@@ -387,7 +417,7 @@ int pinned(void **p, size_t bytes) { return bt_host_alloc_pinned(p, bytes); }
 extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_train_config *cfg,
                             const char *const *paths, int n_paths, bt_batch_callback on_batch,
                             bt_superbatch_callback on_superbatch, void *user) {
-    BT_REQUIRE(net && input && cfg && paths, "bt_train_run: null argument");
+    BT_REQUIRE(net && input && cfg, "bt_train_run: null argument");
     BT_REQUIRE(cfg->batch_size > 0 && cfg->batches_per_superbatch > 0 && cfg->start_superbatch >= 1 &&
                    cfg->end_superbatch >= cfg->start_superbatch,
                "bt_train_run: invalid TrainingSteps");
@@ -412,9 +442,13 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
     const long long total_steps = (long long)(last_superbatch - cfg->start_superbatch + 1) * bps;
 
     // reader.rs:40: skip batch_size * total_batches(start) records (resume)
-    bt_reader *reader = nullptr;
+    bt_reader *reader = static_cast<bt_reader *>(cfg->reader);  // caller's reader (e.g. a binpack source), kept open
+    const bool own_reader = reader == nullptr;
     const uint64_t start_pos = (uint64_t)BG * (uint64_t)bps * (uint64_t)(cfg->start_superbatch - 1);
-    if (int rc = bt_reader_open(paths, n_paths, start_pos, &reader)) return rc;
+    if (own_reader) {
+        BT_REQUIRE(paths, "bt_train_run: no data files and no reader");
+        if (int rc = bt_reader_open(paths, n_paths, start_pos, &reader)) return rc;
+    }
 
     constexpr int RING = 4;
     HostSlot slots[RING];
@@ -450,7 +484,7 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
         bt_host_free_pinned(loss_host), bt_host_free_pinned(lr_host);
         bt_free(loss_dev), bt_free(lr_dev), bt_free(adj_dev);
         bt_stream_destroy(copy_stream), bt_stream_destroy(compute_stream);
-        bt_reader_close(reader);
+        if (own_reader) bt_reader_close(reader);
     };
 #define TRY(x)                \
     do {                      \

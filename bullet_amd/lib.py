@@ -103,7 +103,7 @@ class TrainConfig(C.Structure):
                 ("out_buckets", C.c_int), ("use_win_rate_model", C.c_int), ("threads", C.c_int),
                 ("log_rate", C.c_int), ("wdl_output", C.c_int), ("device_mapper", C.c_int),
                 ("dp_rank", C.c_int), ("dp_world", C.c_int), ("grad_sync", C.c_void_p),
-                ("grad_sync_user", C.c_void_p), ("dp_loss_slot", C.c_int), ("stop_superbatch", C.c_int)]
+                ("grad_sync_user", C.c_void_p), ("dp_loss_slot", C.c_int), ("stop_superbatch", C.c_int), ("reader", C.c_void_p)]
 
 
 BATCH_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_float)
@@ -132,7 +132,7 @@ SYMBOLS = [
     "bt_net_set_optimiser",
     "bt_net_param_count", "bt_net_num_tensors", "bt_net_tensor_size", "bt_net_tensor_offset", "bt_net_create",
     "bt_net_destroy", "bt_net_params", "bt_net_grads", "bt_net_momentum", "bt_net_velocity", "bt_net_set_adamw",
-    "bt_net_flat_size", "bt_net_max_batch", "bt_net_grads_owned", "bt_chessboard_from_str", "bt_measure_loader_throughput",
+    "bt_net_flat_size", "bt_net_max_batch", "bt_net_grads_owned", "bt_chessboard_from_str", "bt_measure_loader_throughput", "bt_reader_open_viribinpack",
     "bt_net_forward_backward", "bt_net_optimiser_step", "bt_net_forward", "bt_net_hint_next_batch",
     "bt_input_init", "bt_input_num_inputs", "bt_input_max_active", "bt_map_batch", "bt_map_batch_device",
     "bt_net_init_weights_host", "bt_lr_at", "bt_wdl_at", "bt_reader_open", "bt_reader_next", "bt_reader_close",
@@ -165,6 +165,10 @@ def load():
         getattr(L, f).argtypes = [C.c_void_p]
     L.bt_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     L.bt_chessboard_from_str.argtypes = [C.c_char_p, C.c_void_p]
+    L.bt_reader_open_viribinpack.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_uint64, C.POINTER(C.c_void_p)]
+    L.bt_reader_next.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.bt_reader_close.argtypes = [C.c_void_p]
     L.bt_measure_loader_throughput.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
     L.bt_free.argtypes = [C.c_void_p]
     L.bt_host_alloc_pinned.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
@@ -365,7 +369,7 @@ class Net:
 
     def train(self, input_desc, paths, batch_size, batches_per_superbatch, end_superbatch, lr, wdl, eval_scale=400.0,
               start_superbatch=1, out_buckets=1, threads=4, log_rate=0, win_rate_model=False, on_batch=None,
-              on_superbatch=None, wdl_output=False, device_mapper=False, dist=None):
+              on_superbatch=None, wdl_output=False, device_mapper=False, dist=None, reader=None):
         """run::train through the C ABI. lr / wdl: LrSched / WdlSched. Returns [(superbatch, running_loss, pos/s)].
         dist: an initialised torch.distributed module -> data-parallel training (bt_train_config.dp_*): `batch_size`
         is the global batch, this rank trains on its shard, and the step buffer (flat gradient + loss sum) is
@@ -406,7 +410,10 @@ class Net:
             if on_batch:
                 on_batch(sb, b, loss)
 
-        cpaths = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+        if reader is not None:  # a bt_reader the caller opened (bt_reader_open_viribinpack), instead of `paths`
+            cfg.reader = reader
+            paths = paths or []
+        cpaths = (C.c_char_p * max(len(paths), 1))(*[p.encode() for p in paths])
         rc = self.L.bt_train_run(self.h, C.byref(input_desc), C.byref(cfg), cpaths, len(paths), BATCH_CB(b_cb),
                                  SUPERBATCH_CB(sb_cb), None)
         if sync_err:

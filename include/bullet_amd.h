@@ -401,6 +401,18 @@ typedef struct bt_reader bt_reader;
  * round and round; start_position is ignored there, as in the reference. */
 int bt_reader_open(const char *const *paths, int n_paths, uint64_t start_position, bt_reader **reader);
 int bt_reader_next(bt_reader *reader, void *dst_records, int count);
+/* ViriBinpackLoader (value/loader/viribinpack.rs:37-152): games in viriformat are replayed into bulletformat positions
+ * on `threads` workers and pass through a shuffle buffer of buffer_size_mb * 2^20 / 32 / 2 positions (Fisher-Yates
+ * over the xorshift of value/loader/rng.rs); files are read in order, round and round. filter = ViriFilter::Custom
+ * (viribinpack.rs:188-206): called for every position before its move with the position as a 32-byte ChessBoard,
+ * the move (viriformat encoding), its eval (white-relative centipawns), the game result for white (1.0 / 0.5 / 0.0)
+ * and the ply inside the game; non-zero keeps the position; NULL keeps all. It runs on the worker threads.
+ * shuffle_seed 0 = seeded from the clock like SimpleRand::with_seed. The wire format itself belongs to the
+ * un-vendored crate viriformat 2.0.1 and is restated (parity unpinned, see csrc/viribinpack.cpp); the crate's
+ * built-in `Filter` is not restated. Use the reader through bt_train_config.reader. */
+typedef int (*bt_viri_filter)(void *user, const void *chessboard32, uint16_t mv, int16_t eval, float wdl, int ply);
+int bt_reader_open_viribinpack(const char *const *paths, int n_paths, size_t buffer_size_mb, int threads,
+                               bt_viri_filter filter, void *user, uint64_t shuffle_seed, bt_reader **reader);
 int bt_reader_close(bt_reader *reader);
 
 /* run::train (run.rs:75-265) for one device: loader thread (reader -> bt_map_batch into a pinned ring) ->
@@ -438,6 +450,9 @@ typedef struct {
      * schedules keep seeing end_superbatch as the end of training -- how a caller checkpoints between superbatches
      * (value.rs:197-208): run to the checkpoint, save, call again with start_superbatch = stop_superbatch + 1. */
     int stop_superbatch;
+    /* non-NULL: a bt_reader the caller opened (bt_reader_open_viribinpack ...) is used instead of `paths`; it is not
+     * repositioned for start_superbatch (the binpack loaders ignore the start, viribinpack.rs:58) and stays open. */
+    void *reader;
 } bt_train_config;
 /* run::measure_max_cpu_throughput (run.rs:47-73): reader + host mapper alone over the schedule of `cfg` (no device
  * work); reports per superbatch when cfg->log_rate > 0 and returns the overall positions per second. */

@@ -195,10 +195,42 @@ namespace loader {
 struct DirectSequentialDataLoader {  // value/loader/direct.rs
     std::vector<std::string> paths;
     explicit DirectSequentialDataLoader(std::vector<std::string> p) : paths(std::move(p)) {}
+    bt_reader *open() const { return nullptr; }  // read by bt_train_run itself, with resume-by-position
 };
 struct InMemoryTextLoader {  // value/loader/text.rs
     std::vector<std::string> paths;
     explicit InMemoryTextLoader(const std::string &p) : paths{"text:" + p} {}
+    bt_reader *open() const { return nullptr; }
+};
+// value/loader/viribinpack.rs. ViriFilter::Custom: (position as a 32-byte ChessBoard, move, eval, wdl) -> keep?
+// (the crate's built-in `Filter` is not restated, see csrc/viribinpack.cpp); an empty function keeps everything.
+using ViriFilter = std::function<bool(const uint8_t *chessboard, uint16_t mv, int16_t eval, float wdl)>;
+struct ViriBinpackLoader {
+    std::vector<std::string> paths;
+    size_t buffer_size_mb;
+    int threads;
+    ViriFilter filter;
+    ViriBinpackLoader(const std::string &path, size_t buffer_mb, int threads_, ViriFilter f = {})
+        : paths{path}, buffer_size_mb(buffer_mb), threads(threads_), filter(std::move(f)) {}
+    static ViriBinpackLoader new_concat_multiple(std::vector<std::string> p, size_t buffer_mb, int threads_,
+                                                 ViriFilter f = {}) {
+        ViriBinpackLoader l(p.at(0), buffer_mb, threads_, std::move(f));
+        l.paths = std::move(p);
+        return l;
+    }
+    bt_reader *open() const {  // `this` must outlive the reader (the filter is called through it)
+        std::vector<const char *> c;
+        for (const auto &p : paths) c.push_back(p.c_str());
+        bt_reader *r = nullptr;
+        bt_viri_filter cb = nullptr;
+        if (filter)
+            cb = [](void *u, const void *rec, uint16_t mv, int16_t eval, float wdl, int) -> int {
+                return static_cast<const ViriBinpackLoader *>(u)->filter(static_cast<const uint8_t *>(rec), mv, eval, wdl);
+            };
+        check(bt_reader_open_viribinpack(c.data(), (int)c.size(), buffer_size_mb, threads, cb,
+                                         const_cast<ViriBinpackLoader *>(this), 0, &r));
+        return r;
+    }
 };
 }  // namespace loader
 
@@ -609,6 +641,11 @@ class ValueTrainer {
         // The loop runs from checkpoint to checkpoint: bt_train_run drains its pipeline when it returns, so the state
         // saved is exactly the one after the last batch of that superbatch (the reference saves inside its
         // superbatch callback, value.rs:197-208); the reader resumes by position like a restarted run (reader.rs:40).
+        struct ReaderGuard {  // loaders that decode (binpacks) hand over one reader for the whole run
+            bt_reader *r;
+            ~ReaderGuard() { bt_reader_close(r); }
+        } guard{data.open()};
+        cfg.reader = guard.r;
         int sb = schedule.steps.start_superbatch;
         while (sb <= schedule.steps.end_superbatch) {
             int stop = sb;

@@ -599,3 +599,39 @@ def test_eval_fen_matches_oracle_forward(wdl):
         else:
             assert abs(val - float(ref[0])) <= 1e-5 * abs(float(ref[0])) + 2e-6
     net.close()
+
+
+def test_train_run_from_a_viribinpack_reader(tmp_path):
+    """bt_train_config.reader: the training loop fed by a ViriBinpackLoader-style reader (games replayed and shuffled
+    on the host) == the same shuffled record stream mapped and stepped by hand."""
+    import test_viribinpack as tv
+    path = tmp_path / "games.vf"
+    path.write_bytes(tv.encode_game(tv.GAME1, {0, 7, 56, 63}, 2, tv.EV1) + tv.encode_game(tv.GAME2, {56}, 0, tv.EV2))
+    cfg = dict(num_inputs=768, nnz=32, ft_out=32, ft_act="screlu", dense=[(1, "identity", False)])
+    idesc, B = lib.make_input_desc("chess768"), 512
+    net = lib.Net(lib.make_net_desc(**cfg), B)
+    net.init_weights(seed=9)
+    h = tv.open_reader([str(path)], 1, 2, 99)
+    per_batch = []
+    net.train(idesc, None, B, 3, 1, lib.LrSched(lib.LR["constant"], 0.001, 0, 0, 0),
+              lib.WdlSched(lib.WDL["constant"], 0.5, 0, 0), threads=2, on_batch=lambda sb, b, l: per_batch.append(l),
+              reader=h)
+    L.bt_reader_close(h)
+    w_run = net.params.clone()
+    net.close()
+    net = lib.Net(lib.make_net_desc(**cfg), B)
+    net.init_weights(seed=9)
+    h = tv.open_reader([str(path)], 1, 2, 99)
+    adj, lrd = torch.tensor([1.0 / B], device="cuda"), torch.tensor([0.001], device="cuda")
+    manual = []
+    for _ in range(3):
+        rec = np.zeros(B * 32, dtype=np.uint8)
+        lib.check(L.bt_reader_next(h, rec.ctypes.data, B))
+        stm, ntm, bk, tg, w = lib.map_batch(idesc, rec, blend=0.5, threads=2)
+        net.forward_backward(net.make_batch(gu.dev(stm), gu.dev(ntm), gu.dev(bk), gu.dev(tg), gu.dev(w)))
+        net.optimiser_step(adj, lrd)
+        torch.cuda.synchronize()
+        manual.append(net.loss.item() / B)
+    L.bt_reader_close(h)
+    assert per_batch == manual and torch.equal(w_run, net.params)
+    net.close()
