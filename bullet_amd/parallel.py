@@ -25,6 +25,11 @@ def allreduce_step_buffers(dist, step_buffer):
     message; a second 4-byte all-reduce would cost a full ring latency for nothing."""
     if dist is None:
         return
+    if step_buffer.is_cuda and dist.get_backend() == "gloo":  # CPU collective (tests / rehearsal): through the host
+        host = step_buffer.cpu()
+        dist.all_reduce(host)
+        step_buffer.copy_(host)
+        return
     dist.all_reduce(step_buffer)
 
 
