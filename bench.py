@@ -92,6 +92,23 @@ def synth_records(count, seed, occupancy="full"):
 CFG2 = dict(num_inputs=768, nnz=32, ft_out=1024, ft_act="screlu", num_buckets=8, dense=[(1, "identity", True)])
 
 
+def halfka(h):  # BASELINE configs[2] / [3]: 16 king buckets -> h x 2 pairwise CReLU -> 16 -> 32 -> 1, 8 output buckets
+    return dict(num_inputs=768 * 16, nnz=32, ft_out=h, ft_act="crelu", pairwise=True, num_buckets=8,
+                dense=[(16, "screlu", True), (32, "screlu", True), (1, "identity", True)], ft_segment=768)
+
+
+# name -> (net, input set, king-bucket layout, workload text). The default `cfg2` is the contract workload; the
+# others are BASELINE's parity-test configurations, runnable with the same flags (single GPU or data parallel).
+NETS = {
+    "cfg2": (CFG2, "chess768", None,
+             "BASELINE configs[1]: Chess768 -> 1024x2 SCReLU -> 1, 8 output buckets, AdamW, fwd+bwd+optimiser step"),
+    "cfg3": (halfka(1024), "chess_buckets", [i // 4 for i in range(64)],
+             "BASELINE configs[2]: HalfKA 16 king buckets -> 1024x2 pairwise -> 16 -> 32 -> 1, 8 output buckets, AdamW"),
+    "cfg4": (halfka(1536), "chess_buckets", [i // 4 for i in range(64)],
+             "BASELINE configs[3]: HalfKA 16 king buckets -> 1536x2 pairwise -> 16 -> 32 -> 1, 8 output buckets, AdamW"),
+}
+
+
 def algorithmic_bytes(kernel, B, nbar, P=2, H=1024, N=32, F=768, K=2048, O=8):
     """ALGORITHMIC bytes per launch (stated in DESIGN.md). nbar = mean active features."""
     ft_fwd = P * B * (nbar * H * 4 + N * 4 + H * 4) + H * 4
@@ -121,6 +138,8 @@ def main():
     ap.add_argument("--records", default=None, metavar="FILE.bf",
                     help="take positions from a bulletformat file (tiled to the batch size) instead of the synthetic "
                          "generator, e.g. tests/golden/batch.bf: real feature skew (not the contract workload)")
+    ap.add_argument("--net", choices=sorted(NETS), default="cfg2",
+                    help="cfg2 = the contract workload (BASELINE configs[1]); cfg3 / cfg4 = the HalfKA multi-layer nets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--live-loader", type=int, default=0, metavar="BATCHES",
@@ -156,7 +175,8 @@ def main():
     B = args.batch
     global_batch = B * world
     n_distinct = 4  # distinct resident batches, rotated
-    idesc = lib.make_input_desc("chess768")
+    netcfg, input_kind, layout, workload = NETS[args.net]
+    idesc = lib.make_input_desc(input_kind, False, layout)
     batches, nbar = [], 0.0
     for i in range(n_distinct):
         if args.records:
@@ -169,15 +189,18 @@ def main():
         nbar += cnt.mean() / n_distinct
         batches.append((stm, ntm, bk, tg, w))
 
-    desc = lib.make_net_desc(**CFG2)
+    desc = lib.make_net_desc(**netcfg)
     net = lib.Net(desc, B)
     # random-init weights of the architecture: Normal(0, sqrt(2/in)) from a fixed stream, same on all ranks
-    rng = np.random.default_rng(1234)
-    init = []
-    for t, n in enumerate(net.sizes):
-        fan_in = 768 if t == 0 else 2048
-        init.append(np.zeros(n, np.float32) if t & 1 else (rng.standard_normal(n) * np.sqrt(2.0 / fan_in)).astype(np.float32))
-    net.set_params(init)
+    if args.net == "cfg2":
+        rng = np.random.default_rng(1234)
+        init = []
+        for t, n in enumerate(net.sizes):
+            fan_in = 768 if t == 0 else 2048
+            init.append(np.zeros(n, np.float32) if t & 1 else (rng.standard_normal(n) * np.sqrt(2.0 / fan_in)).astype(np.float32))
+        net.set_params(init)
+    else:
+        net.init_weights(ft_effective_inputs=32)  # the reference's stream and init_with_effective_input_size(32)
     dev_batches = []
     for stm, ntm, bk, tg, w in batches:
         t = [torch.from_numpy(a).cuda() for a in (stm, ntm, bk, tg, w)]
@@ -186,7 +209,11 @@ def main():
     lr = torch.tensor([1e-3], device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
+    multi_layer = args.net != "cfg2"
+
     def step(i):
+        if multi_layer:  # the next batch is resident: its index structures are built during this step
+            net.hint_next(dev_batches[(i + 1) % n_distinct])
         net.forward_backward(dev_batches[i % n_distinct], stream)
         parallel.allreduce_step_buffers(dist, net.step_buffer)  # grads + loss, one collective; replicas stay identical
         net.optimiser_step(adj, lr, stream)
@@ -233,8 +260,7 @@ def main():
             "value": value, "unit": "positions/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" if not args.records else "file:" + os.path.basename(args.records),
-            "config": {"workload": "BASELINE configs[1]: Chess768 -> 1024x2 SCReLU -> 1, 8 output buckets, AdamW, "
-                                   "fwd+bwd+optimiser step", "batch_per_gpu": B, "global_batch": global_batch,
+            "config": {"workload": workload, "batch_per_gpu": B, "global_batch": global_batch,
                        "occupancy": args.occupancy, "mean_active_features": round(float(nbar), 2),
                        "parallelism": f"dp{world}"},
             "final_loss": loss_per_pos,
@@ -243,12 +269,14 @@ def main():
             out["kernels_us_per_step_warmup"] = {k: round(1e3 * ms / args.warmup, 2) for k, (c, ms) in warm.items()}
         if kern:
             c, ms = kern[dom]
-            abytes = algorithmic_bytes(dom, B, nbar)
+            abytes = algorithmic_bytes(dom, B, nbar, H=netcfg["ft_out"], F=netcfg["num_inputs"],
+                                       K=netcfg["ft_out"] * (1 if netcfg.get("pairwise") else 2),
+                                       O=netcfg["dense"][0][0] * netcfg["num_buckets"])
             launches_per_step = c / args.steps
             avg_s = ms / c * 1e-3
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # PMC passes, see profiles/README.md
-            if os.path.exists(tpath):
+            if os.path.exists(tpath) and args.net == "cfg2":
                 traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
             if abytes:
                 per_launch = abytes / max(launches_per_step, 1.0)
@@ -262,13 +290,14 @@ def main():
                 path = os.path.join(td, "synthetic.bf")
                 synth_records(B * 8, 0xB011E7000 + 99, args.occupancy).tofile(path)
                 nb = args.live_loader
+                assert args.net == "cfg2", "--live-loader is wired for the contract workload"
                 rep = net.train(idesc, [path], B, nb, 2, lib.LrSched(lib.LR["constant"], 1e-3, 0, 0, 0),
                                 lib.WdlSched(lib.WDL["constant"], 0.75, 0, 0), out_buckets=8, threads=args.loader_threads,
                                 device_mapper=not args.host_mapper)
                 out["live_loader"] = {"positions_per_sec": rep[-1][2], "batches": nb, "threads": args.loader_threads,
                                       "mapper": "host" if args.host_mapper else "device",
                                       "note": "second superbatch of bt_train_run: reader + mapper + H2D + step"}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.net == "cfg2":
             out["cpu_baseline"] = cpu_baseline(batches[0], B)
         print(json.dumps(out))
     net.close()
