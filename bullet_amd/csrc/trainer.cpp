@@ -361,7 +361,7 @@ extern "C" int bt_measure_loader_throughput(const bt_input_desc *input, const bt
     for (int sb = cfg->start_superbatch; sb <= cfg->end_superbatch; sb++) {
         for (int batch = 0; batch < bps; batch++) {
             bt_map_opts o;
-            o.out_buckets = cfg->out_buckets, o.blend = bt_wdl_at(&cfg->wdl, batch, sb, cfg->end_superbatch);
+            o.out_buckets = cfg->out_buckets, o.blend = (cfg->wdl_fn ? cfg->wdl_fn(cfg->sched_user, batch, sb, cfg->end_superbatch) : bt_wdl_at(&cfg->wdl, batch, sb, cfg->end_superbatch));
             o.eval_scale = cfg->eval_scale, o.use_win_rate_model = cfg->use_win_rate_model;
             o.wdl_output = cfg->wdl_output, o.threads = cfg->threads;
             int rc = bt_reader_next(reader, records.data(), B);
@@ -569,7 +569,7 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
                 slot = L.free_slots.front();
                 L.free_slots.pop_front();
             }
-            bt_map_opts o = map_opts(bt_wdl_at(&cfg->wdl, batch, sb, cfg->end_superbatch));
+            bt_map_opts o = map_opts((cfg->wdl_fn ? cfg->wdl_fn(cfg->sched_user, batch, sb, cfg->end_superbatch) : bt_wdl_at(&cfg->wdl, batch, sb, cfg->end_superbatch)));
             HostSlot &s = slots[slot];
             s.blend = o.blend;
             int lrc;
@@ -713,7 +713,7 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
         }
         // compute waits for this batch's upload; the learning rate goes through a pinned ring (run.rs:171-173)
         TRY_HIP(hipStreamWaitEvent(bt_stream(compute_stream), uploaded[set], 0));
-        lr_host[ring] = bt_lr_at(&cfg->lr, batch, sb);
+        lr_host[ring] = (cfg->lr_fn ? cfg->lr_fn(cfg->sched_user, batch, sb) : bt_lr_at(&cfg->lr, batch, sb));
         TRY(bt_memcpy_h2d_async(lr_dev + ring, lr_host + ring, sizeof(float), compute_stream));
         const bt_batch bb = dev_batch(set);
         // data parallel: the loss sum sits right behind the flat gradient when there is room, so the exchange of a

@@ -103,7 +103,8 @@ class TrainConfig(C.Structure):
                 ("out_buckets", C.c_int), ("use_win_rate_model", C.c_int), ("threads", C.c_int),
                 ("log_rate", C.c_int), ("wdl_output", C.c_int), ("device_mapper", C.c_int),
                 ("dp_rank", C.c_int), ("dp_world", C.c_int), ("grad_sync", C.c_void_p),
-                ("grad_sync_user", C.c_void_p), ("dp_loss_slot", C.c_int), ("stop_superbatch", C.c_int), ("reader", C.c_void_p)]
+                ("grad_sync_user", C.c_void_p), ("dp_loss_slot", C.c_int), ("stop_superbatch", C.c_int), ("reader", C.c_void_p),
+                ("lr_fn", C.c_void_p), ("wdl_fn", C.c_void_p), ("sched_user", C.c_void_p)]
 
 
 BATCH_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_float)

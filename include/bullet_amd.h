@@ -453,6 +453,11 @@ typedef struct {
     /* non-NULL: a bt_reader the caller opened (bt_reader_open_viribinpack ...) is used instead of `paths`; it is not
      * repositioned for start_superbatch (the binpack loaders ignore the start, viribinpack.rs:58) and stays open. */
     void *reader;
+    /* non-NULL: used instead of `lr` / `wdl` -- any LrScheduler / WdlScheduler (the reference's are traits,
+     * schedule/lr.rs:8-18, wdl.rs:6-14: Sequence, user-defined ...). wdl_fn gets the final superbatch as `max`. */
+    float (*lr_fn)(void *user, int batch, int superbatch);
+    float (*wdl_fn)(void *user, int batch, int superbatch, int max);
+    void *sched_user;
 } bt_train_config;
 /* run::measure_max_cpu_throughput (run.rs:47-73): reader + host mapper alone over the schedule of `cfg` (no device
  * work); reports per superbatch when cfg->log_rate > 0 and returns the overall positions per second. */

@@ -107,65 +107,92 @@ struct AdamWParams {  // crates/trainer/src/optimiser/adam.rs:21-33
 }  // namespace optimiser
 
 // ------------------------------------------------------------------------------------------ trainer::schedule
-namespace lr {  // trainer/schedule/lr.rs
+namespace lr {  // trainer/schedule/lr.rs -- any type with `float lr(int batch, int superbatch) const` is an LrScheduler
+namespace detail {
+inline float at(int kind, float a, float b, int n, int batch, int superbatch) {
+    const bt_lr_sched s{kind, a, b, n, 0};
+    return bt_lr_at(&s, batch, superbatch);
+}
+}  // namespace detail
 struct ConstantLR {
     float value;
-    bt_lr_sched c() const { return {BT_LR_CONSTANT, value, 0.0f, 0, 0}; }
+    float lr(int b, int sb) const { return detail::at(BT_LR_CONSTANT, value, 0.0f, 0, b, sb); }
 };
 struct DropLR {
     float start, gamma;
     int drop;
-    bt_lr_sched c() const { return {BT_LR_DROP, start, gamma, drop, 0}; }
+    float lr(int b, int sb) const { return detail::at(BT_LR_DROP, start, gamma, drop, b, sb); }
 };
 struct StepLR {
     float start, gamma;
     int step;
-    bt_lr_sched c() const { return {BT_LR_STEP, start, gamma, step, 0}; }
+    float lr(int b, int sb) const { return detail::at(BT_LR_STEP, start, gamma, step, b, sb); }
 };
 struct LinearDecayLR {
     float initial_lr, final_lr;
     int final_superbatch;
-    bt_lr_sched c() const { return {BT_LR_LINEAR, initial_lr, final_lr, final_superbatch, 0}; }
+    float lr(int b, int sb) const { return detail::at(BT_LR_LINEAR, initial_lr, final_lr, final_superbatch, b, sb); }
 };
 struct CosineDecayLR {
     float initial_lr, final_lr;
     int final_superbatch;
-    bt_lr_sched c() const { return {BT_LR_COSINE, initial_lr, final_lr, final_superbatch, 0}; }
+    float lr(int b, int sb) const { return detail::at(BT_LR_COSINE, initial_lr, final_lr, final_superbatch, b, sb); }
 };
 struct ExponentialDecayLR {
     float initial_lr, final_lr;
     int final_superbatch;
-    bt_lr_sched c() const { return {BT_LR_EXP, initial_lr, final_lr, final_superbatch, 0}; }
+    float lr(int b, int sb) const { return detail::at(BT_LR_EXP, initial_lr, final_lr, final_superbatch, b, sb); }
 };
 template <class LR>
-struct Warmup {
+struct Warmup {  // lr.rs:166-187
     LR inner;
     int warmup_batches;
-    bt_lr_sched c() const {
-        bt_lr_sched s = inner.c();
-        s.warmup_batches = warmup_batches;
-        return s;
+    float lr(int batch, int superbatch) const {
+        const float base = inner.lr(batch, superbatch);
+        return (superbatch == 1 && batch < warmup_batches) ? base / (float)(warmup_batches - batch) : base;
+    }
+};
+template <class First, class Second>
+struct Sequence {  // lr.rs:193-210
+    First first;
+    Second second;
+    int first_scheduler_final_superbatch;
+    float lr(int batch, int superbatch) const {
+        const int mid = first_scheduler_final_superbatch;
+        return superbatch <= mid ? first.lr(batch, superbatch) : second.lr(batch, superbatch - mid);
     }
 };
 }  // namespace lr
 
-namespace wdl {  // trainer/schedule/wdl.rs
+namespace wdl {  // trainer/schedule/wdl.rs -- `float blend(int batch, int superbatch, int max) const`
 struct ConstantWDL {
     float value;
-    bt_wdl_sched c() const { return {BT_WDL_CONSTANT, value, value, 0}; }
+    float blend(int, int, int) const { return value; }
 };
 struct LinearWDL {
     float start, end;
-    bt_wdl_sched c() const { return {BT_WDL_LINEAR, start, end, 0}; }
+    float blend(int batch, int superbatch, int max) const {
+        const bt_wdl_sched s{BT_WDL_LINEAR, start, end, 0};
+        return bt_wdl_at(&s, batch, superbatch, max);
+    }
 };
 template <class W>
-struct Warmup {
+struct Warmup {  // wdl.rs:51-72
     W inner;
     int warmup_batches;
-    bt_wdl_sched c() const {
-        bt_wdl_sched s = inner.c();
-        s.warmup_batches = warmup_batches;
-        return s;
+    float blend(int batch, int superbatch, int max) const {
+        const float base = inner.blend(batch, superbatch, max);
+        return (superbatch == 1 && batch < warmup_batches) ? base / (float)(warmup_batches - batch) : base;
+    }
+};
+template <class First, class Second>
+struct Sequence {  // wdl.rs:78-95
+    First first;
+    Second second;
+    int first_scheduler_final_superbatch;
+    float blend(int batch, int superbatch, int max) const {
+        const int mid = first_scheduler_final_superbatch;
+        return superbatch <= mid ? first.blend(batch, superbatch, mid) : second.blend(batch, superbatch - mid, max - mid);
     }
 };
 }  // namespace wdl
@@ -619,7 +646,7 @@ class ValueTrainer {
         bt_train_config cfg;
         std::memset(&cfg, 0, sizeof(cfg));
         cfg.batch_size = schedule.steps.batch_size, cfg.batches_per_superbatch = schedule.steps.batches_per_superbatch;
-        cfg.lr = schedule.lr_scheduler.c(), cfg.wdl = schedule.wdl_scheduler.c(), cfg.eval_scale = schedule.eval_scale;
+        set_schedulers(&cfg, schedule);
         cfg.out_buckets = out_buckets_, cfg.use_win_rate_model = win_rate_model_, cfg.threads = settings.threads;
         cfg.log_rate = 128, cfg.wdl_output = wdl_output_, cfg.device_mapper = 0;
         std::vector<const char *> paths;
@@ -727,7 +754,7 @@ class ValueTrainer {
         std::memset(&cfg, 0, sizeof(cfg));
         cfg.batch_size = schedule.steps.batch_size, cfg.batches_per_superbatch = schedule.steps.batches_per_superbatch;
         cfg.start_superbatch = schedule.steps.start_superbatch, cfg.end_superbatch = schedule.steps.end_superbatch;
-        cfg.lr = schedule.lr_scheduler.c(), cfg.wdl = schedule.wdl_scheduler.c(), cfg.eval_scale = schedule.eval_scale;
+        set_schedulers(&cfg, schedule);
         cfg.out_buckets = out_buckets_, cfg.use_win_rate_model = win_rate_model_, cfg.threads = settings.threads;
         cfg.log_rate = 1, cfg.wdl_output = wdl_output_;
         std::vector<const char *> paths;
@@ -738,6 +765,17 @@ class ValueTrainer {
     }
 
   private:
+    // The schedulers are called back from the training loop (the reference's are traits): `schedule` must outlive it.
+    template <class LR, class WDL>
+    static void set_schedulers(bt_train_config *cfg, const TrainingSchedule<LR, WDL> &schedule) {
+        using S = TrainingSchedule<LR, WDL>;
+        cfg->eval_scale = schedule.eval_scale;
+        cfg->sched_user = const_cast<S *>(&schedule);
+        cfg->lr_fn = [](void *u, int batch, int sb) -> float { return static_cast<const S *>(u)->lr_scheduler.lr(batch, sb); };
+        cfg->wdl_fn = [](void *u, int batch, int sb, int max) -> float {
+            return static_cast<const S *>(u)->wdl_scheduler.blend(batch, sb, max);
+        };
+    }
     // (Re)creates the device net for at least `batch` positions, carrying weights and optimiser state across.
     void ensure_net(int batch) {
         check(bt_device_set(device_));

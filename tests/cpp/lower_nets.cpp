@@ -122,6 +122,12 @@ int main() {
                 return l1.forward(h * h);                                            // an op the kernels do not have
             });
     } catch (const Error &) { rejected++; }
+    // schedulers (trainer/schedule/{lr,wdl}.rs): Sequence switches at the midpoint and re-bases the superbatch;
+    // Warmup divides by (warmup_batches - batch) during superbatch 1
+    lr::Sequence<lr::Warmup<lr::ConstantLR>, lr::LinearDecayLR> seq{{{0.001f}, 10}, {0.001f, 0.0001f, 10}, 4};
+    wdl::Sequence<wdl::ConstantWDL, wdl::LinearWDL> wseq{{0.3f}, {0.2f, 0.0f}, 4};
+    std::printf("sched %.9g %.9g %.9g %.9g %.9g | %.9g %.9g %.9g\n", seq.lr(0, 1), seq.lr(9, 1), seq.lr(3, 4), seq.lr(0, 5),
+                seq.lr(0, 14), wseq.blend(0, 2, 14), wseq.blend(0, 5, 14), wseq.blend(0, 14, 14));
     std::printf("rejected=%d\n", rejected);
     return 0;
 }

@@ -6,6 +6,7 @@ prints (0.056420 / 0.052189) and write the checkpoint tree of save_to_checkpoint
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,6 +36,11 @@ def test_example_graphs_lower_to_the_tested_descriptors(tmp_path):
                            "-lbullet_amd", "-Wl,-rpath," + os.path.join(ROOT, "bullet_amd"), "-o", exe])
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.strip().splitlines()
     got = dict(line.split(" ", 1) for line in out if " " in line)
+    sched = [float(x) for x in got.pop("sched").replace("|", " ").split()]
+    f32 = np.float32
+    lin = lambda sb: float(f32(0.001) + f32(0.0001 - 0.001) * f32(sb / 10.0))  # LinearDecayLR re-based after superbatch 4
+    want = [0.001 / 10, 0.001, 0.001, lin(1), 0.0001, 0.3, 0.2, 0.0]  # LinearWDL over max - midpoint = 10 superbatches
+    assert np.allclose(sched, want, rtol=2e-6, atol=1e-9), (sched, want)
     assert got == EXPECTED
     assert out[-1] == "rejected=3"  # graphs outside the family raise instead of being approximated
 
@@ -69,3 +75,21 @@ def test_cpp_examples_reach_the_reference_losses(tmp_path, name, expected):
         size = (768 * 32 + 32 + 64 + 1) * 2
         assert (ck / "quantised.bin").stat().st_size == (size + 63) // 64 * 64
         assert (ck / "raw.bin").stat().st_size == (768 * 32 + 32 + 64 + 1) * 4
+
+
+@pytest.mark.gpu
+def test_cpp_multi_layer_example_trains_and_saves(tmp_path):
+    """examples/progression/4_multi_layer.cpp (= the reference's 4_multi_layer.rs) for one short superbatch: factoriser,
+    per-weight clipping, cosine LR, and the mixed i16 / i8 / f32 saved format with transposes and the factoriser merge."""
+    if not _gpu():
+        pytest.skip("needs a GPU")
+    exe = os.path.join(ROOT, "examples", "bin", "4_multi_layer")
+    r = subprocess.run([exe, GOLDEN, str(tmp_path), "1", "3"], capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    loss = float([ln for ln in r.stdout.splitlines() if ln.startswith("Final loss: ")][0].split()[-1])
+    assert 0.01 < loss < 0.3
+    ck = tmp_path / "4_multi_layer-1"
+    nb, hl = 10, 1024
+    size = 768 * nb * hl * 2 + hl * 2 + hl * 128 + 128 * 4 + 16 * 256 * 4 + 256 * 4 + 32 * 8 * 4 + 8 * 4
+    assert (ck / "quantised.bin").stat().st_size == (size + 63) // 64 * 64
+    assert (ck / "raw.bin").stat().st_size == (768 * nb * hl + hl + hl * 128 + 128 + 16 * 256 + 256 + 32 * 8 + 8) * 4
