@@ -3,6 +3,7 @@
 // ataxx147,factorised}.rs), OutputBuckets::bucket (game/outputs.rs:24-31) and the make_mapper closure
 // (crates/bullet_lib/src/value.rs:77-117), fanned out over worker threads like
 // ModelInputsMapper::map (crates/trainer/src/model/inputs.rs:86-109).  Integer outputs must be bit-exact.
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -83,7 +84,7 @@ inline int map_one(const bt_input_desc *d, const uint8_t *rec, int32_t *stm, int
 }
 
 void map_range(const bt_input_desc *d, const bt_map_opts *o, const uint8_t *records, int lo, int hi, int nnz,
-               int32_t *stm, int32_t *ntm, int32_t *buckets, float *targets, float *weights) {
+               int32_t *stm, int32_t *ntm, int32_t *buckets, float *targets, float *weights, std::atomic<int> *bad_blend) {
     const float rscale = 1.0f / o->eval_scale;
     const bool ataxx = is_ataxx(d);
     for (int k = lo; k < hi; k++) {
@@ -109,7 +110,7 @@ void map_range(const bt_input_desc *d, const bt_map_opts *o, const uint8_t *reco
             bucket = (uint8_t)((uint8_t)__builtin_popcountll(occ) - 2) / (uint8_t)divisor;
         }
         buckets[k] = bucket;
-        weights[k] = 1.0f;
+        weights[k] = o->weight_fn ? o->weight_fn(o->fn_user, rec) : 1.0f;  // value.rs:94
         if (o->wdl_output) {
             targets[3 * (size_t)k] = targets[3 * (size_t)k + 1] = targets[3 * (size_t)k + 2] = 0.0f;
             targets[3 * (size_t)k + result] = 1.0f;
@@ -122,7 +123,12 @@ void map_range(const bt_input_desc *d, const bt_map_opts *o, const uint8_t *reco
                 score = sigmoidf_host(rscale * score);
             }
             const float res = (float)result / 2.0f;
-            targets[k] = o->blend * res + (1.0f - o->blend) * score;
+            float blend = o->blend;
+            if (o->blend_fn) {  // value.rs:113-114
+                blend = o->blend_fn(o->fn_user, rec, blend);
+                if (!(blend >= 0.0f && blend <= 1.0f)) bad_blend->store(1);
+            }
+            targets[k] = blend * res + (1.0f - blend) * score;
         }
     }
 }
@@ -192,8 +198,10 @@ int bt_map_batch(const bt_input_desc *d, const bt_map_opts *o, const void *recor
     int threads = o->threads < 1 ? 1 : o->threads;
     if (threads > count) threads = count > 0 ? count : 1;
     const uint8_t *rec = static_cast<const uint8_t *>(records);
+    std::atomic<int> bad_blend(0);
     if (threads == 1) {
-        map_range(d, o, rec, 0, count, nnz, stm, nstm, buckets, targets, weights);
+        map_range(d, o, rec, 0, count, nnz, stm, nstm, buckets, targets, weights, &bad_blend);
+        BT_REQUIRE(!bad_blend.load(), "WDL proportion must be in [0, 1]");
         return BT_OK;
     }
     // chunks of ceil(count/threads), model/inputs.rs:88-103
@@ -202,9 +210,10 @@ int bt_map_batch(const bt_input_desc *d, const bt_map_opts *o, const void *recor
     for (int t = 0; t < threads; t++) {
         const int lo = t * chunk, hi = std::min(count, lo + chunk);
         if (lo >= hi) break;
-        pool.emplace_back(map_range, d, o, rec, lo, hi, nnz, stm, nstm, buckets, targets, weights);
+        pool.emplace_back(map_range, d, o, rec, lo, hi, nnz, stm, nstm, buckets, targets, weights, &bad_blend);
     }
     for (auto &th : pool) th.join();
+    BT_REQUIRE(!bad_blend.load(), "WDL proportion must be in [0, 1]");
     return BT_OK;
 }
 

@@ -360,7 +360,8 @@ extern "C" int bt_measure_loader_throughput(const bt_input_desc *input, const bt
     if (cfg->log_rate > 0) std::printf("Measuring CPU Throughput\n");
     for (int sb = cfg->start_superbatch; sb <= cfg->end_superbatch; sb++) {
         for (int batch = 0; batch < bps; batch++) {
-            bt_map_opts o;
+            bt_map_opts o = {};
+            o.blend_fn = cfg->blend_fn, o.weight_fn = cfg->weight_fn, o.fn_user = cfg->fn_user;
             o.out_buckets = cfg->out_buckets, o.blend = (cfg->wdl_fn ? cfg->wdl_fn(cfg->sched_user, batch, sb, cfg->end_superbatch) : bt_wdl_at(&cfg->wdl, batch, sb, cfg->end_superbatch));
             o.eval_scale = cfg->eval_scale, o.use_win_rate_model = cfg->use_win_rate_model;
             o.wdl_output = cfg->wdl_output, o.threads = cfg->threads;
@@ -503,6 +504,8 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
         }                                                                            \
     } while (0)
 
+    BT_REQUIRE(!(cfg->device_mapper && (cfg->blend_fn || cfg->weight_fn)),
+               "bt_train_run: per-position closures need the host mapper (device_mapper = 0)");
     const bool dev_map = cfg->device_mapper != 0;
     for (auto &s : slots) {
         if (dev_map) {
@@ -547,7 +550,8 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
     }
 
     auto map_opts = [&](float blend) {
-        bt_map_opts o;
+        bt_map_opts o = {};
+        o.blend_fn = cfg->blend_fn, o.weight_fn = cfg->weight_fn, o.fn_user = cfg->fn_user;
         o.out_buckets = cfg->out_buckets;
         o.blend = blend;
         o.eval_scale = cfg->eval_scale;

@@ -104,7 +104,8 @@ class TrainConfig(C.Structure):
                 ("log_rate", C.c_int), ("wdl_output", C.c_int), ("device_mapper", C.c_int),
                 ("dp_rank", C.c_int), ("dp_world", C.c_int), ("grad_sync", C.c_void_p),
                 ("grad_sync_user", C.c_void_p), ("dp_loss_slot", C.c_int), ("stop_superbatch", C.c_int), ("reader", C.c_void_p),
-                ("lr_fn", C.c_void_p), ("wdl_fn", C.c_void_p), ("sched_user", C.c_void_p)]
+                ("lr_fn", C.c_void_p), ("wdl_fn", C.c_void_p), ("sched_user", C.c_void_p),
+                ("blend_fn", C.c_void_p), ("weight_fn", C.c_void_p), ("fn_user", C.c_void_p)]
 
 
 BATCH_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_float)
@@ -116,7 +117,8 @@ WDL = {"constant": 0, "linear": 1}
 
 class MapOpts(C.Structure):
     _fields_ = [("out_buckets", C.c_int), ("blend", C.c_float), ("eval_scale", C.c_float),
-                ("use_win_rate_model", C.c_int), ("wdl_output", C.c_int), ("threads", C.c_int)]
+                ("use_win_rate_model", C.c_int), ("wdl_output", C.c_int), ("threads", C.c_int),
+                ("blend_fn", C.c_void_p), ("weight_fn", C.c_void_p), ("fn_user", C.c_void_p)]
 
 
 # every symbol include/bullet_amd.h declares (tests/test_abi.py checks the .so exports them all)

@@ -340,6 +340,13 @@ typedef struct {
     int use_win_rate_model; /* value.rs:104-108 */
     int wdl_output;         /* value.rs:96-101: 3-way one-hot target */
     int threads;            /* ModelInputsMapper::map fan-out, model/inputs.rs:86-109 */
+    /* Per-position closures of the builder (value/builder.rs:102-111), host mapper only, called on the worker threads:
+     * blend_fn = wdl_adjust_function(pos, scheduled blend) -> blend used for this position (value.rs:113; the result
+     * must be in [0, 1]); weight_fn = datapoint_weight_function(pos) -> entry weight (value.rs:94; the net must then
+     * be created with use_entry_weights = 1, value/builder.rs:137-140). NULL = identity / 1.0. */
+    float (*blend_fn)(void *user, const void *record32, float blend);
+    float (*weight_fn)(void *user, const void *record32);
+    void *fn_user;
 } bt_map_opts;
 
 /* records: host, count*32 bytes of ChessBoard / AtaxxBoard. Outputs are HOST buffers (pinned
@@ -458,6 +465,10 @@ typedef struct {
     float (*lr_fn)(void *user, int batch, int superbatch);
     float (*wdl_fn)(void *user, int batch, int superbatch, int max);
     void *sched_user;
+    /* bt_map_opts.blend_fn / weight_fn / fn_user for the loop's mapper (not with device_mapper) */
+    float (*blend_fn)(void *user, const void *record32, float blend);
+    float (*weight_fn)(void *user, const void *record32);
+    void *fn_user;
 } bt_train_config;
 /* run::measure_max_cpu_throughput (run.rs:47-73): reader + host mapper alone over the schedule of `cfg` (no device
  * work); reports per superbatch when cfg->log_rate > 0 and returns the overall positions per second. */

@@ -615,9 +615,15 @@ class OptimiserHandle {  // `trainer.optimiser.set_params_for_weight(id, params)
     std::function<void()> apply_;
 };
 
+// wdl_adjust_function / datapoint_weight_function (value/builder.rs:102-111): closures over the position record
+using BlendFn = std::function<float(const uint8_t *position, float blend)>;
+using WeightFn = std::function<float(const uint8_t *position)>;
+
 class ValueTrainer {
   public:
     OptimiserHandle optimiser;
+    BlendFn wdl_adjust;     // set by the builder
+    WeightFn datapoint_weight;
 
     ValueTrainer(graph::Matched m, bt_input_desc input, int out_buckets, int opt_kind, std::vector<SavedFormat> fmt,
                  uint64_t seed, int device, bool wdl_output, bool win_rate_model)
@@ -649,6 +655,15 @@ class ValueTrainer {
         set_schedulers(&cfg, schedule);
         cfg.out_buckets = out_buckets_, cfg.use_win_rate_model = win_rate_model_, cfg.threads = settings.threads;
         cfg.log_rate = 128, cfg.wdl_output = wdl_output_, cfg.device_mapper = 0;
+        cfg.fn_user = this;
+        if (wdl_adjust)
+            cfg.blend_fn = [](void *u, const void *rec, float blend) -> float {
+                return static_cast<ValueTrainer *>(u)->wdl_adjust(static_cast<const uint8_t *>(rec), blend);
+            };
+        if (datapoint_weight)
+            cfg.weight_fn = [](void *u, const void *rec) -> float {
+                return static_cast<ValueTrainer *>(u)->datapoint_weight(static_cast<const uint8_t *>(rec));
+            };
         std::vector<const char *> paths;
         for (const auto &p : data.paths) paths.push_back(p.c_str());
         struct Record {
@@ -868,6 +883,8 @@ class ValueTrainerBuilder {  // crates/bullet_lib/src/value/builder.rs:21-394
     ValueTrainerBuilder &loss_fn(F f) { return loss_ = f(LossOutput{}, LossTarget{}), has_loss_ = true, *this; }
     ValueTrainerBuilder &wdl_output() { return wdl_output_ = true, *this; }
     ValueTrainerBuilder &use_win_rate_model() { return win_rate_ = true, *this; }
+    ValueTrainerBuilder &wdl_adjust_function(BlendFn f) { return blend_fn_ = std::move(f), *this; }
+    ValueTrainerBuilder &datapoint_weight_function(WeightFn f) { return weight_fn_ = std::move(f), *this; }
     ValueTrainerBuilder &seed(uint64_t s) { return seed_ = s, *this; }
     ValueTrainerBuilder &use_device(int ordinal) { return device_ = ordinal, *this; }
 
@@ -875,7 +892,9 @@ class ValueTrainerBuilder {  // crates/bullet_lib/src/value/builder.rs:21-394
     template <class F>
     std::unique_ptr<ValueTrainer> build(F f) {
         graph::Matched m = lower(f);
-        return std::make_unique<ValueTrainer>(m, input_, buckets_, opt_, fmt_, seed_, device_, wdl_output_, win_rate_);
+        auto t = std::make_unique<ValueTrainer>(m, input_, buckets_, opt_, fmt_, seed_, device_, wdl_output_, win_rate_);
+        t->wdl_adjust = blend_fn_, t->datapoint_weight = weight_fn_;
+        return t;
     }
     // The host half of build(): runs the closure and matches the graph; touches no device (tests use it).
     template <class F>
@@ -894,6 +913,7 @@ class ValueTrainerBuilder {  // crates/bullet_lib/src/value/builder.rs:21-394
         if (m.desc.num_inputs != fin) throw Error("Mismatched sizes!");  // l0 inputs vs inputs.num_inputs()
         if (wdl_output_ && m.desc.loss_kind != BT_LOSS_SOFTMAX_CE) throw Error("wdl_output needs softmax_crossentropy_loss");
         m.desc.ft_segment = segment_;
+        m.desc.use_entry_weights = weight_fn_ ? 1 : 0;  // `loss * entry_weights` only then (value/builder.rs:137-140)
         return m;
     }
 
@@ -921,6 +941,8 @@ class ValueTrainerBuilder {  // crates/bullet_lib/src/value/builder.rs:21-394
     bool has_input_ = false, has_loss_ = false, wdl_output_ = false, win_rate_ = false;
     std::vector<SavedFormat> fmt_;
     LossValue loss_{BT_LOSS_SIGMOID_MSE, 2.0f};
+    BlendFn blend_fn_;
+    WeightFn weight_fn_;
     uint64_t seed_ = 198273612;  // value/builder.rs:52
 };
 

@@ -180,3 +180,29 @@ def test_loader_throughput_runs_the_schedule_without_a_device():
     paths = (C.c_char_p * 1)(GOLDEN.encode())
     lib.check(L.bt_measure_loader_throughput(C.byref(idesc), C.byref(cfg), paths, 1, C.byref(pps)))
     assert pps.value > 1e4
+
+
+def test_mapper_closures_wdl_adjust_and_datapoint_weight():
+    """value/builder.rs:102-111 + value.rs:94,113-115: per-position blend adjustment and entry weights"""
+    rec = np.fromfile(GOLDEN, dtype=np.uint8)[:32 * 300]
+    idesc = lib.make_input_desc("chess768")
+    base = lib.map_batch(idesc, rec, out_buckets=8, blend=0.4, threads=1)
+    BLEND = C.CFUNCTYPE(C.c_float, C.c_void_p, C.c_void_p, C.c_float)
+    WEIGHT = C.CFUNCTYPE(C.c_float, C.c_void_p, C.c_void_p)
+    pieces = lambda p: bin(int.from_bytes(C.string_at(p, 8), "little")).count("1")  # noqa: E731
+    blend_fn = BLEND(lambda _u, p, b: b if pieces(p) > 16 else 1.0)                 # endgames: pure game result
+    weight_fn = WEIGHT(lambda _u, p: pieces(p) / 32.0)
+    o = lib.MapOpts(8, 0.4, 400.0, 0, 0, 3, C.cast(blend_fn, C.c_void_p), C.cast(weight_fn, C.c_void_p), None)
+    out = [np.zeros_like(a) for a in base]
+    lib.check(L.bt_map_batch(C.byref(idesc), C.byref(o), rec.ctypes.data, 300, *[a.ctypes.data for a in out]))
+    r = rec.reshape(-1, 32)
+    n_pieces = np.array([bin(int(x)).count("1") for x in r[:, :8].copy().view(np.uint64).reshape(-1)])
+    assert np.array_equal(out[0], base[0]) and np.array_equal(out[2], base[2])
+    assert np.array_equal(out[4], (n_pieces / 32.0).astype(np.float32))
+    end = n_pieces <= 16
+    assert np.array_equal(out[3][~end], base[3][~end])
+    assert np.array_equal(out[3][end], (r[end, 26] / 2.0).astype(np.float32)) and end.any() and (~end).any()
+    bad = BLEND(lambda _u, p, b: 1.5)
+    o = lib.MapOpts(8, 0.4, 400.0, 0, 0, 2, C.cast(bad, C.c_void_p), None, None)
+    assert L.bt_map_batch(C.byref(idesc), C.byref(o), rec.ctypes.data, 300, *[a.ctypes.data for a in out]) == 1
+    assert b"WDL proportion" in L.bt_last_error()
