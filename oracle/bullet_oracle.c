@@ -860,3 +860,64 @@ void orc_net_init(const orc_net_desc *d, uint64_t seed, int ft_eff, float *const
         orc_rng_fill(&r, params[t], n, 0.0f, stdev, 1);
     }
 }
+
+/* ------------------------------------------------------------------ generic index / reduce ops
+ * The ops the lowered graph is made of besides the ones above: concat = pad + pad + add
+ * (model/operations/index.rs:74-81), the pairwise halves and the skip neuron = slices, bias = broadcast, bias
+ * gradients and the loss = reduce-sum, softmax = reduce-max. Shapes are given as (outer, dimen, inner) of the
+ * dimension acted on: outer = product of the dimensions before it, inner = product of those after it
+ * (broadcast: inner includes the dimension itself). Elements are 4 bytes (f32 or i32) for the copying ops. */
+
+/* BroadcastAcrossDimension::apply, index/broadcast.rs:66-80 */
+void orc_broadcast(const uint32_t *in, size_t outer, size_t inner, size_t repeats, uint32_t *out) {
+    for (size_t i = 0; i < outer; i++)
+        for (size_t j = 0; j < inner; j++) {
+            const size_t ld = inner * i;
+            for (size_t r = 0; r < repeats; r++) out[ld * repeats + inner * r + j] = in[ld + j];
+        }
+}
+
+/* PadAcrossDimension::apply, index/pad.rs:76-102 */
+void orc_pad(const uint32_t *in, size_t outer, size_t dimen, size_t inner, size_t before, size_t after, uint32_t value,
+             uint32_t *out) {
+    const size_t middle = before + dimen + after;
+    for (size_t o = 0; o < outer; o++)
+        for (size_t i = 0; i < inner; i++) {
+            const size_t base = middle * inner * o;
+            for (size_t b = 0; b < before; b++) out[base + inner * b + i] = value;
+            for (size_t d = 0; d < dimen; d++) out[base + inner * (before + d) + i] = in[inner * (dimen * o + d) + i];
+            for (size_t a = 0; a < after; a++) out[base + inner * (before + dimen + a) + i] = value;
+        }
+}
+
+/* SliceAcrossDimension::apply, index/slice.rs:74-91 */
+void orc_slice(const uint32_t *in, size_t outer, size_t dimen, size_t inner, size_t start, size_t end, uint32_t *out) {
+    const size_t od = end - start;
+    for (size_t o = 0; o < outer; o++)
+        for (size_t d = 0; d < od; d++)
+            memcpy(out + inner * od * o + inner * d, in + inner * dimen * o + inner * (d + start), inner * 4);
+}
+
+/* ReduceAcrossDimension::apply, linear/reduce.rs:96-120; kind 0 = Sum, 1 = Max, 2 = Min; acc starts at element 0 */
+void orc_reduce_f32(const float *in, size_t outer, size_t dimen, size_t inner, int kind, float *out) {
+    for (size_t i = 0; i < outer; i++)
+        for (size_t j = 0; j < inner; j++) {
+            float acc = in[i * dimen * inner + j];
+            for (size_t k = 1; k < dimen; k++) {
+                const float x = in[i * dimen * inner + k * inner + j];
+                acc = kind == 0 ? acc + x : kind == 1 ? (x > acc ? x : acc) : (x < acc ? x : acc);
+            }
+            out[i * inner + j] = acc;
+        }
+}
+void orc_reduce_i32(const int32_t *in, size_t outer, size_t dimen, size_t inner, int kind, int32_t *out) {
+    for (size_t i = 0; i < outer; i++)
+        for (size_t j = 0; j < inner; j++) {
+            int32_t acc = in[i * dimen * inner + j];
+            for (size_t k = 1; k < dimen; k++) {
+                const int32_t x = in[i * dimen * inner + k * inner + j];
+                acc = kind == 0 ? acc + x : kind == 1 ? (x > acc ? x : acc) : (x < acc ? x : acc);
+            }
+            out[i * inner + j] = acc;
+        }
+}

@@ -231,6 +231,16 @@ void orc_rng_fill(orc_rng *r, float *out, size_t n, float mean, float stdev, int
  * stdev as init_with_effective_input_size does (builder.rs:149-152). */
 void orc_net_init(const orc_net_desc *d, uint64_t seed, int ft_effective_inputs, float *const *params);
 
+/* ------------------------------------------------------------------ generic index / reduce ops
+ * (index/broadcast.rs:66-80, index/pad.rs:76-102, index/slice.rs:74-91, linear/reduce.rs:96-120); 4-byte elements;
+ * (outer, dimen, inner) of the dimension acted on; reduce kind 0 = Sum, 1 = Max, 2 = Min */
+void orc_broadcast(const uint32_t *in, size_t outer, size_t inner, size_t repeats, uint32_t *out);
+void orc_pad(const uint32_t *in, size_t outer, size_t dimen, size_t inner, size_t before, size_t after, uint32_t value,
+             uint32_t *out);
+void orc_slice(const uint32_t *in, size_t outer, size_t dimen, size_t inner, size_t start, size_t end, uint32_t *out);
+void orc_reduce_f32(const float *in, size_t outer, size_t dimen, size_t inner, int kind, float *out);
+void orc_reduce_i32(const int32_t *in, size_t outer, size_t dimen, size_t inner, int kind, int32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -108,3 +108,125 @@ def test_material_count_bucket():
         occ = (1 << n_pieces) - 1
         assert L.orc_material_bucket(occ, 8) == (n_pieces - 2) // 4
         assert L.orc_material_bucket(occ, 1) == 0
+
+
+# ---- generic index / reduce ops: every per-dimension vector of the reference's #[test]s --------------------------
+def _dims(shape, dim, include_dim_in_inner=False):
+    outer = int(np.prod(shape[:dim], dtype=np.int64))
+    inner = int(np.prod(shape[dim + (0 if include_dim_in_inner else 1):], dtype=np.int64))
+    return outer, shape[dim], inner
+
+
+_u32p = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))  # noqa: E731
+_sz = C.c_size_t
+
+
+def test_broadcast_golden_and_inverse():
+    # index/broadcast.rs:160-209: shapes [2,4] and [2,2,2], repeats 2; the inverse (reduce-sum) gives 2 * input
+    cases = [([2, 4], 0, [0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3, 4, 5, 6, 7]),
+             ([2, 4], 1, [0, 1, 2, 3, 0, 1, 2, 3, 4, 5, 6, 7, 4, 5, 6, 7]),
+             ([2, 2, 2], 0, [0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3, 4, 5, 6, 7]),
+             ([2, 2, 2], 1, [0, 1, 2, 3, 0, 1, 2, 3, 4, 5, 6, 7, 4, 5, 6, 7]),
+             ([2, 2, 2], 2, [0, 1, 0, 1, 2, 3, 2, 3, 4, 5, 4, 5, 6, 7, 6, 7])]
+    inp = np.arange(8, dtype=np.int32)
+    for shape, dim, exp in cases:
+        outer, _, inner = _dims(shape, dim, include_dim_in_inner=True)
+        out = np.zeros(16, np.int32)
+        L.orc_broadcast(_u32p(inp), _sz(outer), _sz(inner), _sz(2), _u32p(out))
+        assert out.tolist() == exp, (shape, dim)
+        back = np.zeros(8, np.int32)  # Broadcast <-> Reduce (broadcast.rs:121-124): sum over the repeats
+        L.orc_reduce_i32(ob.ip(out), _sz(outer), _sz(2), _sz(inner), 0, ob.ip(back))
+        assert back.tolist() == (2 * inp).tolist()
+
+
+def test_pad_and_slice_golden():
+    # index/pad.rs:178-223 (pad 1 before and after with 0) and its inverse; index/slice.rs:160-198 (slice 0..1)
+    inp = np.arange(8, dtype=np.int32)
+    pads = [([2, 4], 0, [0, 0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 0, 0, 0, 0]),
+            ([2, 4], 1, [0, 0, 1, 2, 3, 0, 0, 4, 5, 6, 7, 0]),
+            ([2, 2, 2], 0, [0, 0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 0, 0, 0, 0]),
+            ([2, 2, 2], 1, [0, 0, 0, 1, 2, 3, 0, 0, 0, 0, 4, 5, 6, 7, 0, 0]),
+            ([2, 2, 2], 2, [0, 0, 1, 0, 0, 2, 3, 0, 0, 4, 5, 0, 0, 6, 7, 0])]
+    for shape, dim, exp in pads:
+        outer, dimen, inner = _dims(shape, dim)
+        out = np.full(len(exp), -1, np.int32)
+        L.orc_pad(_u32p(inp), _sz(outer), _sz(dimen), _sz(inner), _sz(1), _sz(1), C.c_uint32(0), _u32p(out))
+        assert out.tolist() == exp, (shape, dim)
+        back = np.zeros(8, np.int32)  # Pad <-> Slice
+        L.orc_slice(_u32p(out), _sz(outer), _sz(dimen + 2), _sz(inner), _sz(1), _sz(1 + dimen), _u32p(back))
+        assert back.tolist() == inp.tolist()
+    slices = [([2, 4], 0, [0, 1, 2, 3]), ([2, 4], 1, [0, 4]), ([2, 2, 2], 0, [0, 1, 2, 3]), ([2, 2, 2], 1, [0, 1, 4, 5]),
+              ([2, 2, 2], 2, [0, 2, 4, 6])]
+    for shape, dim, exp in slices:
+        outer, dimen, inner = _dims(shape, dim)
+        out = np.zeros(len(exp), np.int32)
+        L.orc_slice(_u32p(inp), _sz(outer), _sz(dimen), _sz(inner), _sz(0), _sz(1), _u32p(out))
+        assert out.tolist() == exp, (shape, dim)
+
+
+def test_reduce_golden_all_dimensions():
+    # linear/reduce.rs:201-244: shape [8, 2, 4] of iota(64), Sum / Max / Min over each dimension
+    inp = np.arange(64, dtype=np.int32)
+    shape = [8, 2, 4]
+    expected = {
+        (0, 0): lambda i: 224 + 8 * i, (1, 0): lambda i: 4 + 2 * (i % 4) + 16 * (i // 4), (2, 0): lambda i: 6 + 16 * i,
+        (0, 1): lambda i: 56 + i, (1, 1): lambda i: i + 4 * (1 + i // 4), (2, 1): lambda i: 3 + 4 * i,
+        (0, 2): lambda i: i, (1, 2): lambda i: i + 4 * (i // 4), (2, 2): lambda i: 4 * i,
+    }
+    for (dim, kind), fn in expected.items():
+        outer, dimen, inner = _dims(shape, dim)
+        out = np.zeros(64 // shape[dim], np.int32)
+        L.orc_reduce_i32(ob.ip(inp), _sz(outer), _sz(dimen), _sz(inner), kind, ob.ip(out))
+        assert out.tolist() == [fn(i) for i in range(out.size)], (dim, kind)
+        outf = np.zeros(out.size, np.float32)
+        L.orc_reduce_f32(ob.fp(inp.astype(np.float32)), _sz(outer), _sz(dimen), _sz(inner), kind, ob.fp(outf))
+        assert outf.tolist() == [float(fn(i)) for i in range(out.size)]
+
+
+def test_graph_assembled_from_primitive_ops_equals_net_forward():
+    """The oracle's whole-net forward (hard-wired op schedule) against the same net put together op by op the way
+    ModelIR::lower + the rewrite rules do (SURVEY.md 3.2): SparseMatmul per perspective, bias as
+    Broadcast + add, SCReLU, concat as pad + pad + add (model/operations/index.rs:74-81), Matmul, bias,
+    Select by output bucket, sigmoid, squared error, reduce-sum over the batch."""
+    import os
+    from bullet_amd import lib
+    rec = np.fromfile(os.path.join(os.path.dirname(__file__), "golden", "batch.bf"), dtype=np.uint8)[:32 * 257]
+    stm, ntm, bk, tg, w = lib.map_batch(lib.make_input_desc("chess768"), rec, out_buckets=8, blend=0.3, threads=1)
+    B, H, NB = 257, 48, 8
+    cfg = dict(num_inputs=768, nnz=32, ft_out=H, ft_act="screlu", num_buckets=NB, dense=[(1, "identity", True)])
+    d = ob.make_net(**cfg)
+    params = ob.net_init(d, 7)
+    params[1][:] = np.linspace(-0.2, 0.3, H, dtype=np.float32)  # non-zero biases
+    params[3][:] = np.linspace(-0.1, 0.1, NB, dtype=np.float32)
+    l0w, l0b, l1w, l1b = params
+    out_ref = np.zeros(B, np.float32)
+    loss_ref = L.orc_net_forward(C.byref(d), B, ob.ptr_array(params), ob.ip(stm), ob.ip(ntm), ob.ip(bk), ob.fp(tg),
+                                 ob.fp(w), ob.fp(out_ref))
+    u = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))  # noqa: E731
+    hidden = []
+    bias_b = np.zeros(B * H, np.float32)
+    L.orc_broadcast(u(l0b), _sz(1), _sz(H), _sz(B), u(bias_b))          # [H] -> [B][H]
+    for idx in (stm, ntm):
+        acc = np.zeros(B * H, np.float32)
+        L.orc_sparse_matmul_fwd(ob.fp(l0w), ob.ip(idx), ob.fp(acc), B, H, 768, H, 0, 32, 1)
+        x = acc + bias_b                                                  # bias after the sum (builder.rs:145-147)
+        y = np.zeros_like(x)
+        L.orc_act_fwd(3, ob.fp(x), ob.fp(y), _sz(x.size))
+        hidden.append(y)
+    a_pad, b_pad = np.zeros(B * 2 * H, np.float32), np.zeros(B * 2 * H, np.float32)
+    L.orc_pad(u(hidden[0]), _sz(B), _sz(H), _sz(1), _sz(0), _sz(H), C.c_uint32(0), u(a_pad))
+    L.orc_pad(u(hidden[1]), _sz(B), _sz(H), _sz(1), _sz(H), _sz(0), C.c_uint32(0), u(b_pad))
+    h = a_pad + b_pad                                                     # concat
+    y_all = np.zeros(B * NB, np.float32)
+    L.orc_matmul(ob.fp(l1w), ob.fp(h), ob.fp(y_all), 1, NB, 2 * H, B, 1, 1)  # W (NB x 2H) . X (2H x B), column-major
+    b1 = np.zeros(B * NB, np.float32)
+    L.orc_broadcast(u(l1b), _sz(1), _sz(NB), _sz(B), u(b1))
+    y_all = y_all + b1
+    y = np.zeros(B, np.float32)
+    L.orc_select(ob.fp(y_all), ob.ip(bk), ob.fp(y), B, NB, NB)
+    assert np.allclose(y, out_ref, rtol=2e-6, atol=1e-6)
+    s = np.array([L.orc_sigmoid(C.c_float(v)) for v in y], dtype=np.float32)
+    per_pos = (s - tg.reshape(-1)) ** 2
+    total = np.zeros(1, np.float32)
+    L.orc_reduce_f32(ob.fp(per_pos.astype(np.float32)), _sz(1), _sz(B), _sz(1), 0, ob.fp(total))
+    assert abs(float(total[0]) - float(loss_ref)) <= 2e-6 * abs(float(loss_ref))
