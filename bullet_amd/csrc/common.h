@@ -12,6 +12,8 @@
 
 #include "../../include/bullet_amd.h"
 
+int bt_internal_sf_source(const char *const *paths, int n_paths, size_t buffer_size_mb, int threads, bt_sf_filter filter,
+                          void *user, uint64_t shuffle_seed, std::function<int(std::vector<uint8_t> &)> *out_refill);
 // viribinpack.cpp: a source of shuffled 32-byte records for bt_reader (each call delivers one full shuffle buffer)
 int bt_internal_viri_source(const char *const *paths, int n_paths, size_t buffer_size_mb, int threads,
                             bt_viri_filter filter, void *user, uint64_t shuffle_seed,

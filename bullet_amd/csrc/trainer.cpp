@@ -328,6 +328,18 @@ extern "C" int bt_reader_open_viribinpack(const char *const *paths, int n_paths,
     return BT_OK;
 }
 
+extern "C" int bt_reader_open_sfbinpack(const char *const *paths, int n_paths, size_t buffer_size_mb, int threads,
+                                        bt_sf_filter filter, void *user, uint64_t shuffle_seed, bt_reader **out) {
+    BT_REQUIRE(out, "bt_reader_open_sfbinpack: bad arguments");
+    bt_reader *r = new bt_reader();
+    if (int rc = bt_internal_sf_source(paths, n_paths, buffer_size_mb, threads, filter, user, shuffle_seed, &r->refill)) {
+        delete r;
+        return rc;
+    }
+    *out = r;
+    return BT_OK;
+}
+
 extern "C" int bt_reader_close(bt_reader *r) {
     if (!r) return BT_OK;
     if (r->fp) std::fclose(r->fp);

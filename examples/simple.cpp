@@ -55,6 +55,14 @@ int main(int argc, char **argv) {
             10,
         };
         LocalSettings settings{4, nullptr, "checkpoints", 64};
+        // loading from a Viriformat binpack (custom filters only: the crate's built-in `Filter` is not restated)
+        loader::ViriBinpackLoader data_loader_viri("data/run.binpack", 1024, 4);
+        // loading from a SF binpack, with the filter of the reference's example
+        loader::SfBinpackLoader data_loader_sf("data/test80.binpack", 1024, 4, [](const bt_sf_entry &entry) {
+            return entry.ply >= 16 && !entry.in_check && std::abs(entry.score) <= 10000 && entry.move_type == 0 &&
+                   entry.captured_piece == 7;
+        });
+        (void)data_loader_viri, (void)data_loader_sf;
         // loading directly from a `BulletFormat` file
         loader::DirectSequentialDataLoader data_loader({data});
         trainer->run(schedule, settings, data_loader);

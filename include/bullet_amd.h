@@ -354,6 +354,26 @@ typedef struct {
  * weights F32[count]. Slots after the -1 terminator are left untouched (value.rs:86-89). */
 int bt_map_batch(const bt_input_desc *d, const bt_map_opts *o, const void *records, int count, int32_t *stm,
                  int32_t *nstm, int32_t *buckets, float *targets, float *weights);
+/* SfBinpackLoader (value/loader/sfbinpack.rs:50-225): Stockfish binpack files -> every entry that passes `filter` as
+ * a bulletformat position (convert_to_bulletformat, :23-48) -> the same shuffle buffer as bt_reader_open_viribinpack.
+ * The filter sees what the reference's closure reads off a TrainingDataEntry (examples/simple.rs:96-102): score and
+ * result (side-to-move relative, result -1 / 0 / 1), ply, the move to be played, the piece type standing on its
+ * destination (7 = none) and whether the side to move is in check; non-zero keeps the entry, NULL keeps all. The
+ * wire format belongs to the un-vendored crate sfbinpack 0.6.4 and is restated (parity unpinned, see
+ * csrc/sfbinpack.cpp). */
+typedef struct {
+    const void *chessboard; /* the position as the 32-byte ChessBoard it becomes */
+    int16_t score;
+    uint16_t ply;
+    int16_t result;
+    uint8_t move_from, move_to;
+    uint8_t move_type;      /* 0 normal, 1 promotion, 2 castling (move_to = the rook's square), 3 en passant */
+    uint8_t promotion;      /* N B R Q = 0..3 when move_type = 1 */
+    uint8_t captured_piece; /* type on the destination square: P N B R Q K = 0..5, 7 = none */
+    uint8_t in_check;
+} bt_sf_entry;
+typedef int (*bt_sf_filter)(void *user, const bt_sf_entry *entry);
+
 /* The same mapping on the device: records_dev (count*32 bytes, 8-byte aligned) and all outputs are DEVICE buffers;
  * one wave per record, enqueued on `stream` (o->threads is ignored). Indices, terminators and buckets are
  * bit-identical to bt_map_batch; score targets may differ by 1 ulp where the two exp implementations round
@@ -420,6 +440,8 @@ int bt_reader_next(bt_reader *reader, void *dst_records, int count);
 typedef int (*bt_viri_filter)(void *user, const void *chessboard32, uint16_t mv, int16_t eval, float wdl, int ply);
 int bt_reader_open_viribinpack(const char *const *paths, int n_paths, size_t buffer_size_mb, int threads,
                                bt_viri_filter filter, void *user, uint64_t shuffle_seed, bt_reader **reader);
+int bt_reader_open_sfbinpack(const char *const *paths, int n_paths, size_t buffer_size_mb, int threads,
+                             bt_sf_filter filter, void *user, uint64_t shuffle_seed, bt_reader **reader);
 int bt_reader_close(bt_reader *reader);
 
 /* run::train (run.rs:75-265) for one device: loader thread (reader -> bt_map_batch into a pinned ring) ->

@@ -259,6 +259,34 @@ struct ViriBinpackLoader {
         return r;
     }
 };
+// value/loader/sfbinpack.rs. The filter sees a TrainingDataEntry's score / ply / result / move / destination piece /
+// in-check flag (bt_sf_entry), as the closure of examples/simple.rs:96-102 does; an empty function keeps everything.
+using SfFilter = std::function<bool(const bt_sf_entry &entry)>;
+struct SfBinpackLoader {
+    std::vector<std::string> paths;
+    size_t buffer_size_mb;
+    int threads;
+    SfFilter filter;
+    SfBinpackLoader(const std::string &path, size_t buffer_mb, int threads_, SfFilter f = {})
+        : paths{path}, buffer_size_mb(buffer_mb), threads(threads_), filter(std::move(f)) {}
+    static SfBinpackLoader new_concat_multiple(std::vector<std::string> p, size_t buffer_mb, int threads_,
+                                               SfFilter f = {}) {
+        SfBinpackLoader l(p.at(0), buffer_mb, threads_, std::move(f));
+        l.paths = std::move(p);
+        return l;
+    }
+    bt_reader *open() const {  // `this` must outlive the reader
+        std::vector<const char *> c;
+        for (const auto &p : paths) c.push_back(p.c_str());
+        bt_reader *r = nullptr;
+        bt_sf_filter cb = nullptr;
+        if (filter)
+            cb = [](void *u, const bt_sf_entry *e) -> int { return static_cast<const SfBinpackLoader *>(u)->filter(*e); };
+        check(bt_reader_open_sfbinpack(c.data(), (int)c.size(), buffer_size_mb, threads, cb,
+                                       const_cast<SfBinpackLoader *>(this), 0, &r));
+        return r;
+    }
+};
 }  // namespace loader
 
 // ------------------------------------------------------------------------------------------ trainer::save
