@@ -260,3 +260,142 @@ def test_in_check_flag_and_errors(tmp_path):
     h = open_reader([str(trunc)], 1, 1, 1)
     assert L.bt_reader_next(h, out.ctypes.data, 1) != 0 and b"malformed" in L.bt_last_error()
     L.bt_reader_close(h)
+
+
+# ------------------------------------------------------------------------------------------ random playouts
+def fen_of(sq, stm):
+    rows = []
+    for rank in range(7, -1, -1):
+        row, gap = "", 0
+        for file in range(8):
+            pc = sq.get(8 * rank + file)
+            if pc is None:
+                gap += 1
+            else:
+                row += (str(gap) if gap else "") + ("PNBRQK"[pc[1]] if pc[0] == 0 else "pnbrqk"[pc[1]])
+                gap = 0
+        rows.append(row + (str(gap) if gap else ""))
+    return "/".join(rows) + (" b" if stm else " w")
+
+
+def slider_hits(sq, target, by):
+    for s in ray(sq, target, DIAG):
+        if s in sq and sq[s][0] == by and sq[s][1] in (B, Q):
+            return True
+    for s in ray(sq, target, ORTH):
+        if s in sq and sq[s][0] == by and sq[s][1] in (R, Q):
+            return True
+    return False
+
+
+LOST = {0: (0, "long"), 7: (0, "short"), 56: (1, "long"), 63: (1, "short")}
+
+
+def play(sq, stm, castle, frm, to, promo, flag):
+    """-> (board, side, castling rights, en-passant square) after the move; the en-passant square exists only if a
+    pawn can take there without exposing its king to a bishop, rook or queen"""
+    sq, castle = dict(sq), set(castle)
+    pc = sq.pop(frm)
+    ep = None
+    if flag == 2:
+        rook = sq.pop(to)
+        rank, short = frm & 56, to > frm
+        sq[rank | (6 if short else 2)], sq[rank | (5 if short else 3)] = pc, rook
+    else:
+        if flag == 1:
+            sq.pop(to + (8 if stm else -8))
+        sq[to] = (stm, N + promo) if flag == 3 else pc
+    for s in (frm, to):
+        castle.discard(LOST.get(s))
+        if s in (4, 60):
+            castle -= {(s // 56, "long"), (s // 56, "short")}
+    if pc[1] == P and abs(to - frm) == 16 and flag == 0:
+        cand, taker = (frm + to) // 2, stm ^ 1
+        king = [s for s, v in sq.items() if v == (taker, K)]
+        for q in steps(cand, [(-1, 1 if taker else -1), (1, 1 if taker else -1)]):
+            if sq.get(q) == (taker, P):
+                after = {k: v for k, v in sq.items() if k not in (q, to)}
+                after[cand] = (taker, P)
+                if not king or not slider_hits(after, king[0], stm):
+                    ep = cand
+    return sq, stm ^ 1, castle, ep
+
+
+def pseudo_moves(sq, stm, castle, ep):
+    out = []
+    own = {s for s, v in sq.items() if v[0] == stm}
+    for frm in sorted(own):
+        t = sq[frm][1]
+        if t == P:
+            up = -1 if stm else 1
+            dest = [d for d in steps(frm, [(-1, up), (1, up)]) if (d in sq and sq[d][0] != stm) or d == ep]
+            f1 = frm + 8 * up
+            if f1 not in sq:
+                dest.append(f1)
+                if (frm >> 3) == (6 if stm else 1) and f1 + 8 * up not in sq:
+                    dest.append(f1 + 8 * up)
+            for d in dest:
+                if (frm >> 3) == (1 if stm else 6):
+                    out += [(frm, d, pr, 3) for pr in range(4)]
+                else:
+                    out.append((frm, d, 0, 1 if d == ep and d not in sq else 0))
+        elif t == K:
+            out += [(frm, d, 0, 0) for d in steps(frm, DIAG + ORTH) if d not in own]
+            for kind, rook, between in (("short", frm | 7, (5, 6)), ("long", frm & 56, (1, 2, 3))):
+                if (stm, kind) in castle and all((frm & 56) | f not in sq for f in between):
+                    out.append((frm, rook, 0, 2))
+        else:
+            cand = steps(frm, KN) if t == N else ray(sq, frm, (DIAG if t in (B, Q) else []) + (ORTH if t in (R, Q) else []))
+            out += [(frm, d, 0, 0) for d in cand if d not in own]
+    return [m for m in out if sq.get(m[1], (0, 0))[1] != K or m[3] == 2]  # kings stay on the board
+
+
+def test_random_playouts_round_trip(tmp_path):
+    """40 random pseudo-legal games of up to 80 plies (the format indexes pseudo-legal candidate sets, so legality is
+    not needed): encoded by the Python side, decoded by the library, every position compared with the record its
+    FEN parses to. Exercises sliders, promotions, en passant (with the capture-possible rule), lost castling rights."""
+    rng = np.random.default_rng(2024)
+    body, want, viri = b"", [], b""
+    for g in range(40):
+        sq, stm = parse(tv.START + " w")
+        castle, ep = set(ALL), None
+        game, states, scores = [], [], []
+        for ply in range(int(rng.integers(1, 81))):
+            moves = pseudo_moves(sq, stm, castle, ep)
+            if not moves or len(sq) < 3:
+                break
+            special = [m for m in moves if m[3] != 0]
+            mv = special[int(rng.integers(len(special)))] if special and rng.random() < 0.5 else moves[int(rng.integers(len(moves)))]
+            game.append((fen_of(sq, stm),) + mv)
+            states.append((set(castle), ep))
+            scores.append(int(rng.integers(-3000, 3001)))
+            sq, stm, castle, ep = play(sq, stm, castle, *mv)
+        res_white = int(rng.integers(-1, 2))
+        first_stm = parse(game[0][0])[1]
+        body += chain(game, states, scores, 0, res_white if first_stm == 0 else -res_white)
+        whites = []
+        for (fen, *_), s in zip(game, scores):
+            white = s if parse(fen)[1] == 0 else -s
+            whites.append(white)
+            want.append(f"{fen} - - 0 1 | {white} | {['0.0', '0.5', '1.0'][res_white + 1]}")
+        viri += tv.encode_game(game, {0, 7, 56, 63}, res_white + 1, whites)  # the same games in viriformat
+    path = tmp_path / "random.binpack"
+    path.write_bytes(b"BINP" + struct.pack("<I", len(body)) + body)
+    exp = np.zeros((len(want), 32), dtype=np.uint8)
+    for i, line in enumerate(want):
+        lib.check(L.bt_chessboard_from_str(line.encode(), exp[i].ctypes.data))
+    assert len(want) > 800
+    h = open_reader([str(path)], 1, 3, 77)
+    got = np.zeros((16384, 32), dtype=np.uint8)
+    lib.check(L.bt_reader_next(h, got.ctypes.data, 16384))
+    L.bt_reader_close(h)
+    perm, _ = tv.py_shuffle(16384, 77)
+    assert np.array_equal(got, exp[np.arange(16384) % len(want)][perm])
+    # and through the viriformat replay (a move with eval 0 from square 0 to square 0 would read as a terminator:
+    # the generator never makes one -- a1a1 is not a move)
+    vpath = tmp_path / "random.vf"
+    vpath.write_bytes(viri)
+    h = tv.open_reader([str(vpath)], 1, 3, 77)
+    lib.check(L.bt_reader_next(h, got.ctypes.data, 16384))
+    L.bt_reader_close(h)
+    assert np.array_equal(got, exp[np.arange(16384) % len(want)][perm])
