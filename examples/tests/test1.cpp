@@ -38,6 +38,15 @@ int main(int argc, char **argv) {
         std::printf("Expected loss: 0.056420\n");
         std::printf("Final loss: %.6f\n", trainer->last_superbatch_loss());
         std::printf("Eval: %.3fcp\n", 400.0f * trainer->eval("rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1"));
+        // optimiser API round trip: state written, weights scrambled, state loaded back -> same eval; standalone writers
+        const float eval_trained = trainer->eval("rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1");
+        trainer->optimiser.write_to_checkpoint(out_dir + "/manual_state");
+        trainer->optimiser.load_weights_from_file(out_dir + "/test1-10/optimiser_state/weights.bin");
+        trainer->optimiser.reset_state();
+        trainer->optimiser.load_from_checkpoint(out_dir + "/manual_state");
+        trainer->save_quantised(out_dir + "/manual_quantised.bin");
+        trainer->save_unquantised(out_dir + "/manual_raw.bin");
+        if (trainer->eval("rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1") != eval_trained) return 3;
         char got[32];
         std::snprintf(got, sizeof(got), "%.6f", trainer->last_superbatch_loss());
         return std::string(got) == "0.056420" ? 0 : 2;

@@ -17,6 +17,7 @@
 
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -630,17 +631,28 @@ inline Matched match(const NodePtr &output, int perspectives, int num_buckets, i
 // ------------------------------------------------------------------------------------------ ValueTrainer
 class ValueTrainer;
 
-class OptimiserHandle {  // `trainer.optimiser.set_params_for_weight(id, params)` (optimiser.rs:204-206)
+class OptimiserHandle {  // `trainer.optimiser.*` (crates/trainer/src/optimiser.rs:196-236)
   public:
     void set_params_for_weight(const std::string &id, optimiser::AdamWParams p) {
         params_[id] = p;
         if (apply_) apply_();
     }
+    void set_params(optimiser::AdamWParams p) {  // every weight (optimiser.rs:208-212)
+        all_ = p, has_all_ = true, params_.clear();
+        if (apply_) apply_();
+    }
+    inline void reset_state();                                   // optimiser.rs:196-202
+    inline void write_to_checkpoint(const std::string &dir);     // optimiser.rs:218-224: weights / momentum / velocity
+    inline void load_weights_from_file(const std::string &path); // optimiser.rs:226-230: a weights.bin, state untouched
+    inline void load_from_checkpoint(const std::string &dir);    // optimiser.rs:232-236
 
   private:
     friend class ValueTrainer;
     std::map<std::string, optimiser::AdamWParams> params_;
+    optimiser::AdamWParams all_;
+    bool has_all_ = false;
     std::function<void()> apply_;
+    ValueTrainer *owner_ = nullptr;
 };
 
 // wdl_adjust_function / datapoint_weight_function (value/builder.rs:102-111): closures over the position record
@@ -662,6 +674,7 @@ class ValueTrainer {
         weights_.assign(n, 0.0f);  // ModelWeights::new(&definition, seed) (value/builder.rs:145)
         check(bt_net_init_weights_host(&m_.desc, seed, m_.ft_effective_inputs, weights_.data()));
         optimiser.apply_ = [this] { apply_params(); };
+        optimiser.owner_ = this;
     }
     ValueTrainer(const ValueTrainer &) = delete;
     ValueTrainer &operator=(const ValueTrainer &) = delete;
@@ -790,6 +803,18 @@ class ValueTrainer {
         ensure_net(1);
         check(bt_net_load_checkpoint(net_, nullptr, path.c_str()));
     }
+    void save_quantised(const std::string &path) {  // value/save.rs:107-109
+        download();
+        std::vector<bt_saved_format> f;
+        for (const auto &s : fmt_) f.push_back(s.c());
+        check(bt_save_quantised(&m_.desc, weights_.data(), f.data(), (int)f.size(), path.c_str()));
+    }
+    void save_unquantised(const std::string &path) {  // value/save.rs:111-113
+        download();
+        std::vector<bt_saved_format> f;
+        for (const auto &s : fmt_) f.push_back(s.c());
+        check(bt_save_raw(&m_.desc, weights_.data(), f.data(), (int)f.size(), path.c_str()));
+    }
     template <class LR, class WDL, class Loader>
     double measure_max_cpu_throughput(const TrainingSchedule<LR, WDL> &schedule, const LocalSettings &settings,
                                       const Loader &data) {  // value.rs:257-272
@@ -808,6 +833,17 @@ class ValueTrainer {
     }
 
   private:
+    friend class OptimiserHandle;
+    void download() {  // device weights -> weights_
+        ensure_net(1);
+        check(bt_memcpy_d2h_async(weights_.data(), bt_net_params(net_), weights_.size() * sizeof(float), nullptr));
+        check(bt_stream_sync(nullptr));
+    }
+    void upload() {
+        ensure_net(1);
+        check(bt_memcpy_h2d_async(bt_net_params(net_), weights_.data(), weights_.size() * sizeof(float), nullptr));
+        check(bt_stream_sync(nullptr));
+    }
     // The schedulers are called back from the training loop (the reference's are traits): `schedule` must outlive it.
     template <class LR, class WDL>
     static void set_schedulers(bt_train_config *cfg, const TrainingSchedule<LR, WDL> &schedule) {
@@ -846,6 +882,11 @@ class ValueTrainer {
     }
     void apply_params() {
         if (!net_) return;
+        if (optimiser.has_all_)
+            for (int i = 0; i < bt_net_num_tensors(&m_.desc); i++) {
+                const auto &p = optimiser.all_;
+                check(bt_net_set_adamw(net_, i, p.decay, p.beta1, p.beta2, p.min_weight, p.max_weight));
+            }
         for (const auto &kv : optimiser.params_) {
             int t = -1;
             for (int i = 0; i < bt_net_num_tensors(&m_.desc); i++)
@@ -883,6 +924,48 @@ class ValueTrainer {
     bt_net *net_ = nullptr;
     float last_loss_ = 0.0f;
 };
+
+inline void OptimiserHandle::reset_state() {
+    owner_->ensure_net(1);
+    check(bt_net_set_optimiser(owner_->net_, owner_->opt_kind_, 5.0f, 0.5f, 6));  // zeroes the state and the step count
+}
+inline void OptimiserHandle::write_to_checkpoint(const std::string &dir) {
+    ValueTrainer &t = *owner_;
+    t.ensure_net(1);
+    (void)mkdir(dir.c_str(), 0777);
+    std::vector<float> host(t.weights_.size());
+    const struct {
+        const float *dev;
+        const char *file;
+    } parts[3] = {{bt_net_params(t.net_), "/weights.bin"}, {bt_net_momentum(t.net_), "/momentum.bin"},
+                  {bt_net_velocity(t.net_), "/velocity.bin"}};
+    for (const auto &p : parts) {
+        check(bt_memcpy_d2h_async(host.data(), p.dev, host.size() * sizeof(float), nullptr));
+        check(bt_stream_sync(nullptr));
+        check(bt_checkpoint_write(&t.m_.desc, host.data(), (dir + p.file).c_str()));
+    }
+}
+inline void OptimiserHandle::load_weights_from_file(const std::string &path) {
+    owner_->download();  // ids missing from the file keep their values
+    check(bt_checkpoint_read(&owner_->m_.desc, owner_->weights_.data(), path.c_str()));
+    owner_->upload();
+}
+inline void OptimiserHandle::load_from_checkpoint(const std::string &dir) {  // `dir` = .../optimiser_state
+    ValueTrainer &t = *owner_;
+    t.ensure_net(1);
+    std::vector<float> host(t.weights_.size());
+    const struct {
+        float *dev;
+        const char *file;
+    } parts[3] = {{bt_net_params(t.net_), "/weights.bin"}, {bt_net_momentum(t.net_), "/momentum.bin"},
+                  {bt_net_velocity(t.net_), "/velocity.bin"}};
+    for (const auto &p : parts) {
+        std::fill(host.begin(), host.end(), 0.0f);
+        check(bt_checkpoint_read(&t.m_.desc, host.data(), (dir + p.file).c_str()));
+        check(bt_memcpy_h2d_async(p.dev, host.data(), host.size() * sizeof(float), nullptr));
+        check(bt_stream_sync(nullptr));
+    }
+}
 
 // ------------------------------------------------------------------------------------------ ValueTrainerBuilder
 class ValueTrainerBuilder {  // crates/bullet_lib/src/value/builder.rs:21-394

@@ -75,6 +75,11 @@ def test_cpp_examples_reach_the_reference_losses(tmp_path, name, expected):
         size = (768 * 32 + 32 + 64 + 1) * 2
         assert (ck / "quantised.bin").stat().st_size == (size + 63) // 64 * 64
         assert (ck / "raw.bin").stat().st_size == (768 * 32 + 32 + 64 + 1) * 4
+        # trainer.optimiser.write_to_checkpoint / save_quantised / save_unquantised after the run == the checkpoint's files
+        for a, b in (("manual_quantised.bin", "quantised.bin"), ("manual_raw.bin", "raw.bin"),
+                     ("manual_state/weights.bin", "optimiser_state/weights.bin"),
+                     ("manual_state/velocity.bin", "optimiser_state/velocity.bin")):
+            assert (tmp_path / a).read_bytes() == (ck / b).read_bytes(), a
 
 
 @pytest.mark.gpu
