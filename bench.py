@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+LDS_PEAK_GBS = 150000.0  # MI355X_MICROARCH.md, LDS: ~150 TB/s aggregate for ds_read_b64/b128 at ~2.4 GHz
 
 
 # ----------------------------------------------------------------------------- synthetic positions
@@ -284,6 +285,13 @@ def main():
                 out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                                    "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": per_launch}
+                if dom in ("ft_fwd_lds", "ft_bwd_lds"):
+                    # The table tile lives in LDS, so the algorithmic bytes are LDS gathers, not HBM reads (frac > 1
+                    # against HBM is expected). The bound that applies is the LDS array: ~150 TB/s chip-wide
+                    # for ds_read_b128 (MI355X_MICROARCH.md, LDS section), 2/3 of that with the unavoidable
+                    # two-random-rows-per-256-B-line conflicts.
+                    out["roofline"]["lds"] = {"achieved": ach, "peak": LDS_PEAK_GBS, "unit": "GB/s",
+                                              "frac": ach / LDS_PEAK_GBS}
         if args.live_loader > 0 and world == 1:
             import tempfile
             with tempfile.TemporaryDirectory() as td:
