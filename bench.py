@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--records", default=None, metavar="FILE.bf",
                     help="take positions from a bulletformat file (tiled to the batch size) instead of the synthetic "
                          "generator, e.g. tests/golden/batch.bf: real feature skew (not the contract workload)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch positions per GPU (default); strong: --batch is the global batch, split over the GPUs")
     ap.add_argument("--net", choices=sorted(NETS), default="cfg2",
                     help="cfg2 = the contract workload (BASELINE configs[1]); cfg3 / cfg4 = the HalfKA multi-layer nets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -173,8 +175,12 @@ def main():
             dist.init_process_group(backend)
 
     L = lib.load()
-    B = args.batch
-    global_batch = B * world
+    if args.scaling == "strong":  # the reference's fixed global batch, contiguous shards (parallel.shard_range)
+        lo, hi = parallel.shard_range(args.batch, rank, world)
+        B, global_batch = hi - lo, args.batch
+    else:
+        B = args.batch
+        global_batch = B * world
     n_distinct = 4  # distinct resident batches, rotated
     netcfg, input_kind, layout, workload = NETS[args.net]
     idesc = lib.make_input_desc(input_kind, False, layout)
@@ -259,7 +265,7 @@ def main():
         out = {
             "metric": "training positions/sec (whole node) HalfKA-1024 SCReLU net at 1/2/4/8 GPUs",
             "value": value, "unit": "positions/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" if not args.records else "file:" + os.path.basename(args.records),
             "config": {"workload": workload, "batch_per_gpu": B, "global_batch": global_batch,
                        "occupancy": args.occupancy, "mean_active_features": round(float(nbar), 2),
