@@ -4,7 +4,7 @@ set -e
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 rm -rf gpurun_out/tl; mkdir -p gpurun_out/tl
-timeout -s KILL 200 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-profile > gpurun_out/tl/log.txt 2>&1
+timeout -s KILL 200 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-profile $BENCH_ARGS > gpurun_out/tl/log.txt 2>&1
 f=$(find gpurun_out/tl -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
