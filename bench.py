@@ -282,9 +282,12 @@ def main():
             launches_per_step = c / args.steps
             avg_s = ms / c * 1e-3
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # PMC passes, see profiles/README.md
-            if os.path.exists(tpath) and args.net == "cfg2":
-                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+            # PMC passes, see profiles/README.md (cfg2: profiles/hbm_traffic.json; the HalfKA nets: r01_cfg3/)
+            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json" if args.net == "cfg2"
+                                 else f"r01_cfg3/hbm_traffic_{args.net}.json")
+            if os.path.exists(tpath):
+                tab = json.load(open(tpath))
+                traffic = (tab.get(dom + "_any") or tab.get(dom) or {}).get("hbm_bytes_per_launch")
             if abytes:
                 per_launch = abytes / max(launches_per_step, 1.0)
                 ach = per_launch / avg_s / 1e9

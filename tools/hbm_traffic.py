@@ -11,7 +11,11 @@ import sys
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_hbm"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/hbm_traffic.json"
 KERNELS = ["ft_fwd_lds", "ft_index_kernel", "ft_bwd_lds", "ft_bwd_merge", "head_finish_kernel", "dense_fwd_small",
-           "dense_bwd_small_light", "dense_bwd_small", "sum_partials_seq4_kernel", "sum_partials4_kernel", "adamw_kernel"]
+           "dense_bwd_small_light", "dense_bwd_small", "sum_partials_seq4_kernel", "sum_partials4_kernel", "adamw_kernel",
+           # the HalfKA multi-layer nets (bench.py --net cfg3 / cfg4)
+           "ft_bwd_lds_any", "ft_bwd_merge_grp", "ft_group_count", "ft_group_scan", "ft_group_place", "bucket_perm_kernel",
+           "dense_mfma_fwd", "dense_mfma_dx", "dense_mfma_dw", "dense_mfma_sum", "dense_tail_kernel", "dense_tail_sum",
+           "dense_gz_kernel", "factor_expand_kernel", "factor_reduce_kernel"]
 
 
 def avg(path, counter):
