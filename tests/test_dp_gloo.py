@@ -89,10 +89,15 @@ def test_two_rank_data_parallel_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
     ref_params, ref_losses = _train(0, 1, False)
     (_, p0, l0), (_, p1, l1) = res
     for a, b in zip(p0, p1):

@@ -68,10 +68,15 @@ def test_two_rank_train_run_matches_single_process(device_mapper):
     procs = [ctx.Process(target=_worker, args=(r, world, port, device_mapper, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=100) for _ in range(world)], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        res = sorted([q.get(timeout=100) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:  # never leave a rank behind (a stuck rendezvous would otherwise outlive the test run)
+        for p in procs:
+            if p.is_alive():
+                p.kill()
     for r in res:
         assert not isinstance(r[1], str), r[1]
     (_, l0, sb0, p0), (_, l1, sb1, p1) = res
