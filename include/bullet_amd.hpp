@@ -759,7 +759,10 @@ class ValueTrainer {
         std::vector<int32_t> stm(nnz), ntm(nnz);
         int32_t bucket = 0;
         float target[3] = {0, 0, 0}, weight = 1.0f;
-        bt_map_opts o{out_buckets_, 1.0f, 1.0f, win_rate_model_, wdl_output_, 1};
+        bt_map_opts o;
+        std::memset(&o, 0, sizeof(o));
+        o.out_buckets = out_buckets_, o.blend = 1.0f, o.eval_scale = 1.0f;  // make_mapper(1.0, ConstantWDL { value: 1.0 })
+        o.use_win_rate_model = win_rate_model_, o.wdl_output = wdl_output_, o.threads = 1;
         check(bt_map_batch(&input_, &o, rec, 1, stm.data(), ntm.data(), &bucket, target, &weight));
         const int width = m_.desc.dense_out[m_.desc.n_dense - 1];
         char *dev = nullptr;
