@@ -175,7 +175,8 @@ void do_move(Pos *p, const Move &m) {
         p->sq[rank | (shortc ? 6 : 2)] = piece;
         p->sq[rank | (shortc ? 5 : 3)] = rook;
     } else {
-        if (m.type == 3) p->sq[m.to + (colour ? 8 : -8)] = 0xFF;
+        const int taken = m.to + (colour ? 8 : -8);
+        if (m.type == 3 && taken >= 0 && taken < 64) p->sq[taken] = 0xFF;  // (range check: malformed input only)
         p->sq[m.to] = m.type == 1 ? (uint8_t)((colour << 3) | (KNIGHT + m.promo)) : piece;
         p->sq[m.from] = 0xFF;
     }
@@ -293,6 +294,7 @@ bool unpack_stem(const uint8_t *s, Pos *p, Move *mv, int *score, int *ply, int *
         if (nib < 12) {
             p->sq[q] = (uint8_t)(((nib & 1) << 3) | (nib >> 1));
         } else if (nib == 12) {  // pawn that has just made a double push: rank 4 = white, rank 5 = black
+            if ((q >> 3) != 3 && (q >> 3) != 4) return false;
             const int colour = (q >> 3) == 3 ? 0 : 1;
             p->sq[q] = (uint8_t)((colour << 3) | PAWN);
             p->ep = colour ? q + 8 : q - 8;

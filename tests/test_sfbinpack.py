@@ -399,3 +399,23 @@ def test_random_playouts_round_trip(tmp_path):
     lib.check(L.bt_reader_next(h, got.ctypes.data, 16384))
     L.bt_reader_close(h)
     assert np.array_equal(got, exp[np.arange(16384) % len(want)][perm])
+
+
+def test_garbage_chunks_fail_cleanly(tmp_path):
+    """random bytes behind a valid chunk header: the decoder must report a malformed binpack (or, by luck, decode
+    something), never crash -- stems, bit reader and move replay are all bounds-checked"""
+    rng = np.random.default_rng(5)
+    out = np.zeros((4, 32), dtype=np.uint8)
+    for trial in range(200):
+        n = int(rng.integers(34, 400))
+        body = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        if trial % 2:  # a valid stem followed by garbage movetext
+            sq, stm = parse(tv.START + " w")
+            body = stem(sq, stm, ALL, None, (12, 28, 0, 0), 10, 0, 0) + struct.pack(">H", 40) + body
+        path = tmp_path / f"g{trial}.binpack"
+        path.write_bytes(b"BINP" + struct.pack("<I", len(body)) + body)
+        h = open_reader([str(path)], 1, 1, 1)
+        rc = L.bt_reader_next(h, out.ctypes.data, 4)
+        assert rc in (0, 4)
+        L.bt_reader_close(h)
+        path.unlink()
