@@ -684,6 +684,15 @@ class ValueTrainer {
 
     const bt_net_desc &desc() const { return m_.desc; }
 
+    // Data-parallel training (no counterpart in the reference): one process per GPU, each created with
+    // use_device(local rank); `sync` must sum `n` floats at `buf` over all ranks, in place, in `stream` order (e.g.
+    // ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, comm, (hipStream_t)stream)). The schedule's batch_size stays
+    // the global batch; every rank must be given the same files (and, for binpack loaders, the same shuffle seed).
+    using GradSync = int (*)(void *user, float *buf_dev, size_t n, void *stream);
+    void data_parallel(int rank, int world, GradSync sync, void *user) {
+        dp_rank_ = rank, dp_world_ = world, dp_sync_ = sync, dp_user_ = user;
+    }
+
     // value.rs:141-211: superbatch loop, checkpoints every save_rate superbatches + at the end, log.txt
     template <class LR, class WDL, class Loader>
     void run(const TrainingSchedule<LR, WDL> &schedule, const LocalSettings &settings, const Loader &data) {
@@ -696,6 +705,7 @@ class ValueTrainer {
         set_schedulers(&cfg, schedule);
         cfg.out_buckets = out_buckets_, cfg.use_win_rate_model = win_rate_model_, cfg.threads = settings.threads;
         cfg.log_rate = 128, cfg.wdl_output = wdl_output_, cfg.device_mapper = 0;
+        cfg.dp_rank = dp_rank_, cfg.dp_world = dp_world_, cfg.grad_sync = dp_sync_, cfg.grad_sync_user = dp_user_;
         cfg.fn_user = this;
         if (wdl_adjust)
             cfg.blend_fn = [](void *u, const void *rec, float blend) -> float {
@@ -926,6 +936,9 @@ class ValueTrainer {
     std::vector<float> weights_;
     bt_net *net_ = nullptr;
     float last_loss_ = 0.0f;
+    int dp_rank_ = 0, dp_world_ = 1;
+    GradSync dp_sync_ = nullptr;
+    void *dp_user_ = nullptr;
 };
 
 inline void OptimiserHandle::reset_state() {
