@@ -74,7 +74,7 @@ struct BtProfScope {
     int id;
     hipStream_t s;
     bool on;
-    BtProfScope(int id_, hipStream_t s_) : id(id_), s(s_), on(bt_prof_enabled(id_)) {
+    BtProfScope(int id_, hipStream_t s_, bool on_) : id(id_), s(s_), on(on_) {  // on_: bt_prof_enabled(id), asked ONCE per launch
         if (on) bt_prof_record(id, s, true);
     }
     ~BtProfScope() {
@@ -86,13 +86,24 @@ struct BtProfScope {
 // bt_attach_stop_event(id, ev) arms it for the calling thread's next launch of kernel `id`.
 void bt_attach_stop_event(int kernel_id, hipEvent_t ev);
 hipEvent_t bt_take_stop_event(int kernel_id);
+// Profiled launches carry their two timing events on the kernel's own dispatch packet as well (start / stop of
+// hipExtLaunchKernelGGL): the elapsed time is the kernel's execution time, and no extra packet sits in front of the
+// next kernel (bracketing with hipEventRecord cost ~11 us per step for one kernel). A launch that already carries a
+// completion event falls back to the bracket.
+bool bt_prof_take_pair(int id, hipEvent_t *a, hipEvent_t *b);
 #define BT_LAUNCH(id, stream, kernel, grid, block, lds, ...)                                        \
     do {                                                                                            \
-        BtProfScope prof_scope_(id, stream);                                                        \
-        if (hipEvent_t stop_ev_ = bt_take_stop_event(id))                                           \
-            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, stop_ev_, 0, __VA_ARGS__); \
-        else                                                                                        \
-            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                      \
+        hipEvent_t stop_ev_ = bt_take_stop_event(id), pa_ = nullptr, pb_ = nullptr;                 \
+        const bool prof_ = bt_prof_enabled(id);                                                     \
+        if (prof_ && !stop_ev_ && bt_prof_take_pair(id, &pa_, &pb_)) {                              \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, pa_, pb_, 0, __VA_ARGS__);      \
+        } else {                                                                                    \
+            BtProfScope prof_scope_(id, stream, prof_);                                             \
+            if (stop_ev_)                                                                           \
+                hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, stop_ev_, 0, __VA_ARGS__); \
+            else                                                                                    \
+                hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                  \
+        }                                                                                           \
     } while (0)
 
 // ---- internal cross-file entry points (not in the public header)

@@ -30,6 +30,8 @@ struct Profiler {
     std::vector<ProfRec> recs;
     hipEvent_t pending = nullptr;
     unsigned long long filter = ~0ull;  // bit i set = kernel id i is timed
+    int every = 1;                      // time every n-th launch of a kernel id (bt_profile_set_sampling)
+    unsigned seen[BTK_COUNT] = {0};
 };
 thread_local Profiler g_prof;
 const char *const kKernelNames[BTK_COUNT] = {
@@ -38,7 +40,11 @@ const char *const kKernelNames[BTK_COUNT] = {
     "dense_bwd_dw_kernel", "sum_partials_kernel", "sigmoid_mse_kernel", "adamw_kernel"};
 }  // namespace
 
-bool bt_prof_enabled(int id) { return g_prof.on && ((g_prof.filter >> id) & 1ull); }
+bool bt_prof_enabled(int id) {
+    Profiler &p = g_prof;
+    if (!p.on || !((p.filter >> id) & 1ull)) return false;
+    return (p.seen[id]++ % (unsigned)p.every) == 0;
+}
 
 void bt_prof_record(int id, hipStream_t s, bool begin) {
     Profiler &p = g_prof;
@@ -53,6 +59,14 @@ void bt_prof_record(int id, hipStream_t s, bool begin) {
         p.recs.push_back({id, p.pending, e});
         p.pending = nullptr;
     }
+}
+
+bool bt_prof_take_pair(int id, hipEvent_t *a, hipEvent_t *b) {
+    Profiler &p = g_prof;
+    if (p.used + 2 > p.pool.size()) return false;  // pool exhausted: stop recording rather than allocate mid-run
+    *a = p.pool[p.used++], *b = p.pool[p.used++];
+    p.recs.push_back({id, *a, *b});
+    return true;
 }
 
 namespace {
@@ -81,7 +95,15 @@ int bt_profile_start(int max_launches) {
     p.recs.clear();
     p.pending = nullptr;
     p.filter = ~0ull;
+    p.every = 1;
+    for (unsigned &s : p.seen) s = 0;
     p.on = true;
+    return BT_OK;
+}
+
+int bt_profile_set_sampling(int every) {
+    BT_REQUIRE(every >= 1, "bt_profile_set_sampling: every must be >= 1");
+    g_prof.every = every;
     return BT_OK;
 }
 

@@ -127,7 +127,7 @@ SYMBOLS = [
     "bt_device_count", "bt_device_set", "bt_device_props", "bt_device_sync", "bt_malloc", "bt_free",
     "bt_host_alloc_pinned", "bt_host_free_pinned", "bt_stream_create", "bt_stream_destroy", "bt_stream_sync",
     "bt_memset_async", "bt_memcpy_h2d_async", "bt_memcpy_d2h_async", "bt_memcpy_d2d_async",
-    "bt_profile_start", "bt_profile_set_filter", "bt_profile_stop", "bt_profile_num_kernels", "bt_profile_kernel_name",
+    "bt_profile_start", "bt_profile_set_filter", "bt_profile_set_sampling", "bt_profile_stop", "bt_profile_num_kernels", "bt_profile_kernel_name",
     "bt_ft_forward", "bt_ft_backward_workspace_bytes", "bt_ft_backward", "bt_ft_build_index",
     "bt_ft_backward_prebuilt", "bt_ft_forward_prebuilt", "bt_ft_segment_violations",
     "bt_dense_forward", "bt_dense_backward_workspace_bytes", "bt_dense_backward",
@@ -249,10 +249,12 @@ def check(rc):
         raise BtError(f"[{rc}] {load().bt_last_error().decode()}")
 
 
-def profile_start(max_launches=100000, only=None):
-    """only: iterable of kernel names to time (None = all)"""
+def profile_start(max_launches=100000, only=None, every=1):
+    """only: iterable of kernel names to time (None = all); every: time every n-th launch of each"""
     L = load()
     check(L.bt_profile_start(max_launches))
+    if every > 1:
+        check(L.bt_profile_set_sampling(every))
     if only is not None:
         names = {L.bt_profile_kernel_name(i).decode(): i for i in range(L.bt_profile_num_kernels())}
         mask = 0

@@ -83,6 +83,10 @@ int bt_memcpy_d2d_async(void *dst, const void *src, size_t bytes, void *stream);
 int bt_profile_start(int max_launches);
 /* restrict timing to the kernels whose id bit is set (after bt_profile_start); default all */
 int bt_profile_set_filter(unsigned long long kernel_mask);
+/* time only every n-th launch of each selected kernel (after bt_profile_start; default 1): a timed launch carries
+ * profiling timestamps on its dispatch packet, which costs the stream ~10 us, so a caller that wants an average
+ * over a run without slowing it samples */
+int bt_profile_set_sampling(int every);
 int bt_profile_stop(int *counts, double *total_ms, int n_ids);
 int bt_profile_num_kernels(void);
 const char *bt_profile_kernel_name(int id);
