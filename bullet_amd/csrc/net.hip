@@ -717,6 +717,7 @@ int bt_net_set_optimiser(bt_net *n, int kind, float n_sma_threshold, float alpha
             if (int rc = dmalloc(&n->slow, n->n_params)) return rc;
         BT_HIP(hipMemset(n->slow, 0, n->n_params * sizeof(float)));  // ranger.rs:71: slow weights start at zero
     }
+    BT_HIP(hipStreamSynchronize(nullptr));  // the fills ran on the NULL stream: done before any (non-blocking) stream steps
     return BT_OK;
 }
 

@@ -174,7 +174,13 @@ int bt_malloc(void **ptr, size_t bytes) {
     *ptr = nullptr;
     if (bytes == 0) return BT_OK;
     BT_HIP(hipMalloc(ptr, bytes));
-    hipError_t e = hipMemset(*ptr, 0, bytes);  // Buffer::zeroed, buffer.rs:112-131
+    // Buffer::zeroed, buffer.rs:112-131. The memset runs on the NULL stream and returns before it has executed; the
+    // library's own streams are non-blocking (no implicit order against the NULL stream), so without the wait a
+    // first write on such a stream -- e.g. the 4-byte upload of 1/batch in bt_train_run -- could be overtaken by the
+    // zero fill (seen as a replica training with adj = 0, about 1 run in 15 with two processes on one GPU). The
+    // reference syncs the device around every malloc as well (crates/gpu/src/runtime.rs:102-151).
+    hipError_t e = hipMemset(*ptr, 0, bytes);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) {
         (void)hipFree(*ptr);
         *ptr = nullptr;

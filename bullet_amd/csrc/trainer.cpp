@@ -470,6 +470,8 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
     hipEvent_t uploaded[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr}, slot_copied[RING] = {nullptr};
     constexpr int LOSS_RING = 4;
     hipEvent_t loss_ready[LOSS_RING] = {nullptr};
+    float lr_slot[LOSS_RING] = {0.0f};
+    bool lr_slot_set[LOSS_RING] = {false};
     float *loss_host = nullptr, *lr_host = nullptr, *loss_dev = nullptr, *lr_dev = nullptr, *adj_dev = nullptr;
     std::vector<uint8_t> records((size_t)BG * 32);
     int rc = BT_OK;
@@ -542,6 +544,7 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
             TRY(bt_malloc((void **)&d.records, (size_t)B * 32));
             TRY_HIP(hipMemset(d.stm, 0, sizeof(int32_t) * (size_t)B * nnz));  // (slots behind a terminator are never written)
             TRY_HIP(hipMemset(d.nstm, 0, sizeof(int32_t) * (size_t)B * nnz));
+            TRY_HIP(hipStreamSynchronize(nullptr));  // NULL-stream fills do not order against the non-blocking copy stream
         }
     }
     TRY(bt_stream_create(&copy_stream));
@@ -729,12 +732,19 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
         }
         // compute waits for this batch's upload; the learning rate goes through a pinned ring (run.rs:171-173)
         TRY_HIP(hipStreamWaitEvent(bt_stream(compute_stream), uploaded[set], 0));
-        lr_host[ring] = (cfg->lr_fn ? cfg->lr_fn(cfg->sched_user, batch, sb) : bt_lr_at(&cfg->lr, batch, sb));
-        TRY(bt_memcpy_h2d_async(lr_dev + ring, lr_host + ring, sizeof(float), compute_stream));
+        // (a copy only when this ring slot does not hold the value yet: every packet on the compute stream costs a
+        // few microseconds of bubble, and most schedules change the rate once per superbatch or never)
+        const float lr_now = (cfg->lr_fn ? cfg->lr_fn(cfg->sched_user, batch, sb) : bt_lr_at(&cfg->lr, batch, sb));
+        if (!lr_slot_set[ring] || std::memcmp(&lr_slot[ring], &lr_now, sizeof(float)) != 0) {
+            lr_host[ring] = lr_slot[ring] = lr_now, lr_slot_set[ring] = true;
+            TRY(bt_memcpy_h2d_async(lr_dev + ring, lr_host + ring, sizeof(float), compute_stream));
+        }
         const bt_batch bb = dev_batch(set);
         // data parallel: the loss sum sits right behind the flat gradient when there is room, so the exchange of a
         // step is one collective over n + 1 floats
-        float *loss_at = loss_slot ? bt_net_grads(net) + bt_net_flat_size(net) : loss_dev + ring;
+        // single device: the step writes its loss sum straight into the pinned (device-visible) host ring -- one
+        // 4-byte store over PCIe instead of a copy packet on the compute stream
+        float *loss_at = loss_slot ? bt_net_grads(net) + bt_net_flat_size(net) : dp ? loss_dev + ring : loss_host + ring;
         TRY(bt_net_forward_backward(net, compute_stream, &bb, loss_at));
         if (dp) {
             auto sync = [&](float *buf, size_t n) -> int {
@@ -749,7 +759,7 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
         }
         TRY(bt_net_optimiser_step(net, compute_stream, adj_dev, lr_dev + ring));
         TRY_HIP(hipEventRecord(consumed[set], bt_stream(compute_stream)));
-        TRY(bt_memcpy_d2h_async(loss_host + ring, loss_at, sizeof(float), compute_stream));
+        if (dp) TRY(bt_memcpy_d2h_async(loss_host + ring, loss_at, sizeof(float), compute_stream));
         TRY_HIP(hipEventRecord(loss_ready[ring], bt_stream(compute_stream)));
         pending.push_back({sb, batch});
 
