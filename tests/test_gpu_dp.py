@@ -19,17 +19,24 @@ if not torch.cuda.is_available():
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "batch.bf")
 CFG = dict(num_inputs=768, nnz=32, ft_out=64, ft_act="screlu", num_buckets=8, dense=[(1, "identity", True)])
+# a king-bucketed multi-layer net (HalfKA-style): segment-grouped FT kernels, bucket-sorted MFMA layer, fused tail and
+# the next-batch hints of the training loop, all under the data-parallel exchange
+LAYOUT = [0, 0, 1, 1] * 2 + [2] * 8 + [3] * 16
+CFG_MULTI = dict(num_inputs=768 * 4, nnz=32, ft_out=128, ft_act="crelu", pairwise=True, num_buckets=8, ft_segment=768,
+                 dense=[(16, "screlu", True), (32, "screlu", True), (1, "identity", True)])
 BATCH, BPS, SBS = 1001, 3, 2  # odd batch: uneven shards
 
 
-def _run(dist, device_mapper):
+def _run(dist, device_mapper, kind="single"):
     from bullet_amd import lib, parallel
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
     lo, hi = parallel.shard_range(BATCH, rank, world)
-    net = lib.Net(lib.make_net_desc(**CFG), hi - lo)
-    net.init_weights(seed=11)
+    multi = kind == "multi"
+    net = lib.Net(lib.make_net_desc(**(CFG_MULTI if multi else CFG)), hi - lo)
+    net.init_weights(seed=11, ft_effective_inputs=32 if multi else 0)
     losses = []
-    rep = net.train(lib.make_input_desc("chess768"), [GOLDEN], BATCH, BPS, SBS,
+    idesc = lib.make_input_desc("chess_buckets_mirrored", False, LAYOUT) if multi else lib.make_input_desc("chess768")
+    rep = net.train(idesc, [GOLDEN], BATCH, BPS, SBS,
                     lib.LrSched(lib.LR["constant"], 0.001, 0, 0, 0), lib.WdlSched(lib.WDL["constant"], 0.3, 0, 0),
                     out_buckets=8, threads=2, on_batch=lambda sb, b, l: losses.append(l),
                     device_mapper=device_mapper, dist=dist)
@@ -38,7 +45,7 @@ def _run(dist, device_mapper):
     return losses, [r[1] for r in rep], params
 
 
-def _worker(rank, world, port, device_mapper, q):
+def _worker(rank, world, port, device_mapper, q, kind="single"):
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
     sys.path.insert(0, os.path.dirname(here))
@@ -48,15 +55,15 @@ def _worker(rank, world, port, device_mapper, q):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        q.put((rank,) + _run(dist, device_mapper))
+        q.put((rank,) + _run(dist, device_mapper, kind))
     except Exception as e:  # report instead of hanging the parent on q.get
         q.put((rank, repr(e), None, None))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("device_mapper", [False, True])
-def test_two_rank_train_run_matches_single_process(device_mapper):
+@pytest.mark.parametrize("device_mapper,kind", [(False, "single"), (True, "single"), (True, "multi")])
+def test_two_rank_train_run_matches_single_process(device_mapper, kind):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -65,7 +72,7 @@ def test_two_rank_train_run_matches_single_process(device_mapper):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, device_mapper, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, device_mapper, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -81,7 +88,7 @@ def test_two_rank_train_run_matches_single_process(device_mapper):
         assert not isinstance(r[1], str), r[1]
     (_, l0, sb0, p0), (_, l1, sb1, p1) = res
     assert l0 == l1 and sb0 == sb1 and np.array_equal(p0, p1)  # replicas bit-identical
-    ref_l, ref_sb, ref_p = _run(None, device_mapper)
+    ref_l, ref_sb, ref_p = _run(None, device_mapper, kind)
     assert len(l0) == BPS * SBS == len(ref_l)
     for a, b in zip(l0, ref_l):
         assert abs(a - b) <= 1e-5 * abs(b)
