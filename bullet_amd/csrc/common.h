@@ -88,15 +88,16 @@ void bt_attach_stop_event(int kernel_id, hipEvent_t ev);
 hipEvent_t bt_take_stop_event(int kernel_id);
 // Profiled launches carry their two timing events on the kernel's own dispatch packet as well (start / stop of
 // hipExtLaunchKernelGGL): the elapsed time is the kernel's execution time, and no extra packet sits in front of the
-// next kernel (bracketing with hipEventRecord cost ~11 us per step for one kernel). A launch that already carries a
-// completion event falls back to the bracket.
+// next kernel (bracketing with hipEventRecord measured the waits in front of a kernel as well). A launch that also
+// carries a completion event records that one separately while it is being timed.
 bool bt_prof_take_pair(int id, hipEvent_t *a, hipEvent_t *b);
 #define BT_LAUNCH(id, stream, kernel, grid, block, lds, ...)                                        \
     do {                                                                                            \
         hipEvent_t stop_ev_ = bt_take_stop_event(id), pa_ = nullptr, pb_ = nullptr;                 \
         const bool prof_ = bt_prof_enabled(id);                                                     \
-        if (prof_ && !stop_ev_ && bt_prof_take_pair(id, &pa_, &pb_)) {                              \
+        if (prof_ && bt_prof_take_pair(id, &pa_, &pb_)) {                                           \
             hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, pa_, pb_, 0, __VA_ARGS__);      \
+            if (stop_ev_) (void)hipEventRecord(stop_ev_, stream); /* timed: the completion event gets its own packet */ \
         } else {                                                                                    \
             BtProfScope prof_scope_(id, stream, prof_);                                             \
             if (stop_ev_)                                                                           \
