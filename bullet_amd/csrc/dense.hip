@@ -9,6 +9,8 @@
 // stream, so they are written as fused dot-product kernels: only the selected bucket's rows are ever
 // computed (the reference computes all buckets with a GEMM, then discards), and the SelectPad zeros of
 // the backward are never materialised.  Summation orders are fixed => bit-reproducible.
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -1499,6 +1501,14 @@ int dense_validate(const bt_dense_desc *d, const char *who) {
 
 }  // namespace
 
+// Scratch of bt_dense_backward_static (include/bullet_amd.h): BT_STATIC_SCRATCH_BYTES of device memory that every GPU
+// the library runs on holds until the process ends. Host code never passes `scratch` itself to a kernel or a memset:
+// only the per-device address obtained with hipGetSymbolAddress.
+static __device__ __align__(256) unsigned char scratch[BT_STATIC_SCRATCH_BYTES];
+static constexpr int kMaxScratchDevices = 64;
+static void *g_scratch_ptr[kMaxScratchDevices] = {nullptr};
+static std::mutex g_scratch_mutex;
+
 // ---- internal entry points used by net.hip (declared in common.h)
 // bucket-sorted position order for the mid-size bucketed layers (see g_dense_tab.perm)
 bool bt_internal_dense_wants_perm(const bt_dense_desc *d) {
@@ -1745,6 +1755,36 @@ int bt_dense_backward(void *stream, const bt_dense_desc *d, const float *w, cons
     const size_t nw = (size_t)rows * d->in;
     if (int rc = sum_partials_launch(s, part_w, nr, nw, dw)) return rc;
     return sum_partials_launch(s, part_b, nr, (size_t)rows, dbias);
+}
+
+// bt_dense_backward for callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid
+// hipMalloc): the partial-sum workspace is the file-scope device array `scratch` instead of a caller buffer. The
+// array's name is only a host-side stand-in; its device address is looked up once per device (each GPU holds its
+// own copy at its own address) and that pointer is what the kernels get. No hipMalloc / hipFree on this path.
+int bt_dense_backward_static(void *stream, const bt_dense_desc *d, const float *w, const float *x, const int32_t *bucket,
+                             const float *y, const float *grad_y, float *dw, float *dbias, float *grad_x) {
+    if (int rc = dense_validate(d, "bt_dense_backward_static")) return rc;
+    const size_t need = bt_dense_backward_workspace_bytes(d);
+    BT_REQUIRE(need > 0 && need <= (size_t)BT_STATIC_SCRATCH_BYTES,
+               "bt_dense_backward_static: this shape needs %zu bytes of scratch, the static buffer holds %zu", need,
+               (size_t)BT_STATIC_SCRATCH_BYTES);
+    int dev = -1;
+    BT_HIP(hipGetDevice(&dev));
+    BT_REQUIRE(dev >= 0 && dev < kMaxScratchDevices, "bt_dense_backward_static: device ordinal %d out of range", dev);
+    void *ptr = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[dev]) {
+            void *p = nullptr;
+            BT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+            BT_REQUIRE(p, "bt_dense_backward_static: hipGetSymbolAddress returned a null address");
+            g_scratch_ptr[dev] = p;
+        }
+        ptr = g_scratch_ptr[dev];
+    }
+    // every partial the reduction kernels read is written by the kernels of this same call, so nothing has to be
+    // cleared between calls; calls that overlap on one GPU (two streams, two threads) would race on the array
+    return bt_dense_backward(stream, d, w, x, bucket, y, grad_y, dw, dbias, grad_x, ptr, BT_STATIC_SCRATCH_BYTES);
 }
 
 int bt_sigmoid_mse(void *stream, int batch, const float *y, const float *targets, const float *entry_weights,

@@ -130,7 +130,7 @@ SYMBOLS = [
     "bt_profile_start", "bt_profile_set_filter", "bt_profile_set_sampling", "bt_profile_stop", "bt_profile_num_kernels", "bt_profile_kernel_name",
     "bt_ft_forward", "bt_ft_backward_workspace_bytes", "bt_ft_backward", "bt_ft_build_index",
     "bt_ft_backward_prebuilt", "bt_ft_forward_prebuilt", "bt_ft_segment_violations",
-    "bt_dense_forward", "bt_dense_backward_workspace_bytes", "bt_dense_backward",
+    "bt_dense_forward", "bt_dense_backward_workspace_bytes", "bt_dense_backward", "bt_dense_backward_static",
     "bt_sigmoid_mse", "bt_loss", "bt_adamw", "bt_radam", "bt_lookahead", "bt_weight_clip", "bt_weight_decay",
     "bt_net_set_optimiser",
     "bt_net_param_count", "bt_net_num_tensors", "bt_net_tensor_size", "bt_net_tensor_offset", "bt_net_create",
@@ -194,6 +194,7 @@ def load():
     L.bt_dense_forward.argtypes = [C.c_void_p, C.POINTER(DenseDesc)] + [C.c_void_p] * 5
     L.bt_dense_backward_workspace_bytes.argtypes = [C.POINTER(DenseDesc)]
     L.bt_dense_backward.argtypes = [C.c_void_p, C.POINTER(DenseDesc)] + [C.c_void_p] * 9 + [C.c_size_t]
+    L.bt_dense_backward_static.argtypes = [C.c_void_p, C.POINTER(DenseDesc)] + [C.c_void_p] * 8
     L.bt_sigmoid_mse.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
     L.bt_loss.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                           C.c_void_p, C.c_void_p]

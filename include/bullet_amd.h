@@ -182,6 +182,18 @@ int bt_dense_backward(void *stream, const bt_dense_desc *desc, const float *w, c
                       const int32_t *bucket, const float *y, const float *grad_y, float *dw, float *dbias,
                       float *grad_x, void *workspace, size_t workspace_bytes);
 
+/* bt_dense_backward without a workspace argument and without any allocation. It has NO counterpart in the reference
+ * (whose Function::prealloc owns all intermediates, function.rs:180-196); it is for callers that cannot call
+ * hipMalloc: code under HIP graph capture, tight serving loops, harnesses that forbid allocation. The partial sums
+ * live in a file-scope device array of BT_STATIC_SCRATCH_BYTES inside the library (each GPU holds its own copy until
+ * the process ends); a shape whose bt_dense_backward_workspace_bytes() exceeds that is rejected with BT_ERR_INVALID.
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams or threads) race. Results
+ * are bit-identical to bt_dense_backward. */
+#define BT_STATIC_SCRATCH_BYTES (16u << 20)
+int bt_dense_backward_static(void *stream, const bt_dense_desc *desc, const float *w, const float *x,
+                             const int32_t *bucket, const float *y, const float *grad_y, float *dw, float *dbias,
+                             float *grad_x);
+
 /* sigmoid + squared error (+ entry weight) + batch sum and its gradient in one pass:
  * model/operations/pointwise.rs:141-165, model/builder.rs:351-354, value/builder.rs:137-142,
  * derivative rules binary.rs:101-123 and dfo.rs:105-119.
