@@ -242,6 +242,10 @@ def test_full_size_config2_properties():
     loss_ref = ob.lib().orc_net_forward(C.byref(do), 16384, ob.ptr_array(params), ob.ip(stm), ob.ip(ntm), ob.ip(bk),
                                         ob.fp(tg), ob.fp(w), None)
     assert abs(l1 - loss_ref) <= 1e-5 * abs(loss_ref)
+    # every gradient tensor at the full size against the oracle's backward pass (same bar as test_net_step_vs_oracle)
+    _, grads_ref, _ = ob.net_fwd_bwd(do, params, stm, ntm, bk, tg, w)
+    for t, (a, b) in enumerate(zip(net.get_tensors(g1), grads_ref)):
+        gu.assert_close(a, b, rtol=2e-4, atol=2e-5 * max(float(np.abs(b).max()), 1e-6), what=f"cfg2 full size: grad tensor {t}")
     # every position has exactly one own king (types 5 => features 320..383 stm) per perspective, so
     # sum over king features of dW0 columns == bias gradient contribution of that perspective; both
     # perspectives: sum_f in kings(stm)+kings(ntm as seen) ... checked through total mass instead:
@@ -290,13 +294,16 @@ def test_next_batch_hint_changes_nothing(name):
         assert losses == runs[0][0] and torch.equal(params, runs[0][1])
 
 
-def test_full_size_config3_properties():
-    """BASELINE configs[2] at its full size (HalfKA, 16 king buckets, F = 12288 -> 1024x2 pairwise -> 16 -> 32 -> 1,
-    8 output buckets, B = 16384, real positions): size-independent checks of the segment-grouped path.
+@pytest.mark.parametrize("hidden", [1024, 1536])
+def test_full_size_config3_config4_properties(hidden):
+    """BASELINE configs[2] (H = 1024) and configs[3] (H = 1536: the per-GPU net of the data-parallel config,
+    examples/progression/4_multi_layer.rs:66-87) at full size (HalfKA, 16 king buckets, F = 12288 -> Hx2 pairwise ->
+    16 -> 32 -> 1, 8 output buckets, B = 16384, real positions): checks of the segment-grouped path.
     (a) bit-identical gradients run to run; (b) same loss bits and the same gradients (summation-order bar) as the
-    any-shape kernels without the segment promise; (c) king-column sums of dW0 == 2 x bias gradient; (d) loss vs oracle."""
+    any-shape kernels without the segment promise; (c) king-column sums of dW0 == 2 x bias gradient; (d) loss and
+    (e) every gradient tensor vs the oracle."""
     layout = [i // 4 for i in range(64)]
-    cfg = dict(num_inputs=768 * 16, nnz=32, ft_out=1024, ft_act="crelu", pairwise=True, num_buckets=8,
+    cfg = dict(num_inputs=768 * 16, nnz=32, ft_out=hidden, ft_act="crelu", pairwise=True, num_buckets=8,
                dense=[(16, "screlu", True), (32, "screlu", True), (1, "identity", True)])
     (stm, ntm, bk, tg, w), = fixture_batches("chess_buckets", layout, False, 8, 0.75, 1)
     do = ob.make_net(**cfg)
@@ -320,13 +327,17 @@ def test_full_size_config3_properties():
     assert l_seg == l_any  # (b) the forward pass keeps every summation order
     for t, (a, b) in enumerate(zip(g_seg, g_any)):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-5 * float(b.abs().max()), msg=lambda m: f"tensor {t}: {m}")
-    gw, gb = g_seg[0].view(16, 768, 1024).double(), g_seg[1].double()
+    gw, gb = g_seg[0].view(16, 768, hidden).double(), g_seg[1].double()
     kings = gw[:, 320:384].sum((0, 1)) + gw[:, 384 + 320:768].sum((0, 1))  # own + opponent king columns, all buckets
     torch.testing.assert_close(kings, 2 * gb, rtol=2e-4, atol=1e-4 * float(gb.abs().max()))  # (c)
     assert float(gb.abs().max()) > 0
     loss_ref = ob.lib().orc_net_forward(C.byref(do), 16384, ob.ptr_array(params), ob.ip(stm), ob.ip(ntm), ob.ip(bk),
                                         ob.fp(tg), ob.fp(w), None)
     assert abs(l_seg - loss_ref) <= 1e-5 * abs(loss_ref)  # (d)
+    _, grads_ref, _ = ob.net_fwd_bwd(do, params, stm, ntm, bk, tg, w)  # (e)
+    for t, (a, b) in enumerate(zip(g_seg, grads_ref)):
+        gu.assert_close(a.cpu().numpy(), b, rtol=2e-4, atol=2e-5 * max(float(np.abs(b).max()), 1e-6),
+                        what=f"H={hidden} full size: grad tensor {t}")
 
 
 @pytest.mark.parametrize("hidden,expected", [(32, "0.056420"), (128, "0.044886")])

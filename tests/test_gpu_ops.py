@@ -127,6 +127,9 @@ SEG_CASES = [
     (1500, 128, 768, 16, 32, "screlu", 0, 2, 128, 0, True),  # HalfKA-16 shape, skewed buckets, some empty
     (2100, 32, 768, 10, 32, "screlu", 0, 1, 96, 32, True),   # single input, sliced weights (stride/offset)
     (520, 64, 64, 8, 8, "relu", 0, 2, 64, 0, False),         # small segments (whole table would fit: forced)
+    # the FT of BASELINE configs[3] (HalfKA-16 x 1536 pairwise, 4_multi_layer.rs:79-81): 48 row tiles of 16 + 16 rows
+    (1300, 1536, 768, 16, 32, "crelu", 1, 2, 1536, 0, False),
+    (900, 1536, 768, 16, 32, "crelu", 1, 2, 1536, 0, True),  # the same with skewed king buckets
 ]
 
 
