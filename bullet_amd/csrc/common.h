@@ -162,6 +162,9 @@ int bt_internal_dense_forward_loss(void *stream, const bt_dense_desc *d, const f
                                    float *loss_partials, int *n_loss_partials);
 bool bt_internal_dense_forward_loss_ok(const bt_dense_desc *d);
 
+// allocates the second index-buffer set of bt_net_hint_next_batch now (instead of on the first hint)
+int bt_internal_net_enable_hints(bt_net *net);
+
 // ---- device-side activation helpers (semantics: dfo.rs:47-103, pointwise.rs:54-139) ----
 __device__ __forceinline__ float bt_act_fwd(int act, float v) {
     switch (act) {

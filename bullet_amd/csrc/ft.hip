@@ -30,11 +30,24 @@ __host__ __device__ inline int ft_sorted_cap(int nnz, int cols) { return (FT_CHU
 // 4-pair blocks of a chunk's padded list (rounded so LDS arrays behind it stay 16-B aligned)
 __host__ __device__ inline int ft_blk_cap(int nnz, int cols) { return (ft_sorted_cap(nnz, cols) / 4 + 7) & ~7; }
 
-// tests: BT_FT_FORCE_GENERIC=1 runs the any-shape kernels on every shape
-bool force_generic() {
-    const char *e = getenv("BT_FT_FORCE_GENERIC");
-    return e && e[0] == '1';
-}
+// Test switches, read from the environment when the library is loaded and again only when a test asks for it
+// (bt_internal_reload_env): BT_FT_FORCE_GENERIC=1 runs the any-shape kernels on every shape, BT_FT_FORCE_GROUPED=1
+// the segment-grouped ones wherever a segment is given, BT_FT_FWD_ITEM / BT_FT_BWD_CHUNKS override the item sizes.
+struct FtEnv {
+    bool force_generic = false, force_grouped = false;
+    int fwd_item = 0, bwd_chunks = 0;
+    FtEnv() { reload(); }
+    void reload() {
+        auto num = [](const char *name) {
+            const char *e = getenv(name);
+            return e && e[0] ? atoi(e) : 0;
+        };
+        force_generic = num("BT_FT_FORCE_GENERIC") == 1, force_grouped = num("BT_FT_FORCE_GROUPED") != 0;
+        fwd_item = num("BT_FT_FWD_ITEM"), bwd_chunks = num("BT_FT_BWD_CHUNKS");
+    }
+};
+FtEnv g_ft_env;
+bool force_generic() { return g_ft_env.force_generic; }
 
 struct float4_t {
     float x, y, z, w;
@@ -824,15 +837,6 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
 // FUSED: the incoming gradient is not read from memory but formed on the fly from a one-output dense head,
 // grad_out[b][k*out_w + c] = gz[b] * W1[bucket[b]][k*out_w + c]  (Matmul::backward dX = W^T dY with a single
 // selected row, matmul.rs:117-123 + select.rs:93-110), so the [B][2H] gradient buffer never exists.
-#ifdef BT_EXP_TIMING2
-__device__ unsigned long long bt_dbg2[16];
-#endif
-#ifdef BT_EXP_TIMING
-__device__ unsigned long long bt_dbg[8];
-#define BT_T(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&bt_dbg[i], t_ - t_last); t_last = t_; } } while (0)
-#else
-#define BT_T(i) do { } while (0)
-#endif
 struct FtFusedSrc {
     const float *gz;        // [B] gradient w.r.t. the head's pre-activation
     const float *w1;        // head weights, column-major [w1_rows][n_inputs*out_w]
@@ -979,20 +983,15 @@ __device__ __forceinline__ void ft_bwd_lds_body(const float *__restrict__ grad_o
             r_srt[i] = gs[min(q, srt_vec - 1)];
         }
     };
-#ifdef BT_EXP_TIMING
-    unsigned long long t_last = __builtin_readcyclecounter();
-#endif
     if (c_lo < c_hi) {
         load_eids(c_lo);
         prefetch(c_lo);
     }
-    BT_T(0);
     for (int c = c_lo; c < c_hi; c++) {
         const int cb = c % chunks_per_input;
         const int kc = c / chunks_per_input;
         const int n_e = GRP ? r_ne : min(FT_CHUNK, d.batch - cb * FT_CHUNK);
         __syncthreads();  // previous chunk's readers are done with gt / srt / blkf
-        BT_T(1);
 #pragma unroll
         for (int pass = 0; pass < NPASS; pass++) {
             const int el = el0 + pass * 128;
@@ -1045,17 +1044,11 @@ __device__ __forceinline__ void ft_bwd_lds_body(const float *__restrict__ grad_o
             const int qq = threadIdx.x + i * LDS_THREADS;
             if (qq < srt_vec) reinterpret_cast<lds_u4_t *>(srt)[qq] = r_srt[i];
         }
-        BT_T(2);
         __syncthreads();
-        BT_T(3);
         if (threadIdx.x == 0) span[(c + 1) & 1] = 0;  // next chunk's counters (their writers come after the next barrier)
         if (threadIdx.x < NGRP) hrank[((c + 1) & 1) * NGRP + threadIdx.x] = 0;
         if (c + 1 < c_hi) prefetch(c + 1);
 
-        BT_T(4);
-#ifdef BT_EXP_TIMING2
-        unsigned long long tw0 = __builtin_readcyclecounter();
-#endif
         const int b0 = grp * q, b1 = min(nblk, b0 + q);
         // A run that began in an earlier group can only be the first one here: its sum is parked in h_part and
         // added after the groups before it (rank = distance to the group that owns the run's start), so every
@@ -1135,10 +1128,6 @@ __device__ __forceinline__ void ft_bwd_lds_body(const float *__restrict__ grad_o
                 }
             }
         }
-#ifdef BT_EXP_TIMING2
-        if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) atomicAdd(&bt_dbg2[threadIdx.x >> 6], __builtin_readcyclecounter() - tw0);
-#endif
-        BT_T(5);
         const int max_rank = *cur_span;  // written before the barrier above
         for (int r = 1; r <= max_rank; r++) {
             __syncthreads();
@@ -1150,9 +1139,7 @@ __device__ __forceinline__ void ft_bwd_lds_body(const float *__restrict__ grad_o
             }
         }
     }
-    BT_T(6);
     __syncthreads();
-    BT_T(7);
     float *pw = partial_w + (size_t)cg * tc * d.stride;
     for (int q = threadIdx.x; q < tc * 8; q += LDS_THREADS) {
         const int f = q >> 3, t8 = q & 7;
@@ -1272,11 +1259,6 @@ struct FtPlan {
     size_t off_segof, off_blkcnt, off_elist, off_chunks, off_fitems, off_bitems, off_counts, off_segitems;
 };
 
-int env_int(const char *name, int dflt) {
-    const char *e = getenv(name);
-    return e && e[0] ? atoi(e) : dflt;
-}
-
 int ft_validate(const bt_ft_desc *d, const char *who) {
     BT_REQUIRE(d, "%s: null descriptor", who);
     BT_REQUIRE(d->batch > 0 && d->rows > 0 && d->cols > 0 && d->nnz > 0, "%s: Mismatched sizes! (non-positive dim)", who);
@@ -1318,7 +1300,7 @@ int ft_plan(const bt_ft_desc *d, FtPlan *p) {
     const long long E = (long long)d->n_inputs * d->batch;
     p->nseg = d->segment > 0 ? d->cols / d->segment : 1;
     p->grouped = d->segment > 0 && p->nseg > 1 && p->nseg <= 256 && !force_generic() &&
-                 (!ft_lds_fits(d, d->cols, false) || env_int("BT_FT_FORCE_GROUPED", 0)) &&
+                 (!ft_lds_fits(d, d->cols, false) || g_ft_env.force_grouped) &&
                  ft_lds_fits(d, d->segment, true) && d->nnz % 4 == 0 && d->nnz <= 32 &&
                  (size_t)bt_div_up(E, GRP_BLOCK) * p->nseg * sizeof(int) <= 128 * 1024;
     p->tc = p->grouped ? d->segment : d->cols;
@@ -1354,7 +1336,7 @@ int ft_plan(const bt_ft_desc *d, FtPlan *p) {
         const int tgt_f = std::max(1, 512 / p->ntiles), tgt_b = std::max(1, 512 / p->ntiles);
         int fi = (int)std::min<long long>(4096, std::max<long long>(128, (E / tgt_f + 127) / 128 * 128));
         int gc = std::max(1, std::min(16, p->max_chunks / tgt_b));
-        p->fwd_item = env_int("BT_FT_FWD_ITEM", fi), p->g_ch = env_int("BT_FT_BWD_CHUNKS", gc);
+        p->fwd_item = g_ft_env.fwd_item > 0 ? g_ft_env.fwd_item : fi, p->g_ch = g_ft_env.bwd_chunks > 0 ? g_ft_env.bwd_chunks : gc;
         p->fwd_item = std::max(128, p->fwd_item / 128 * 128), p->g_ch = std::max(1, p->g_ch);
         p->grp_blocks = bt_div_up(E, GRP_BLOCK);
         p->max_fitems = bt_div_up(E, p->fwd_item) + p->nseg;
@@ -1643,25 +1625,13 @@ int bt_internal_ft_build_sorted(void *stream, const bt_ft_desc *d, const int32_t
     return BT_OK;
 }
 
+// tests change the switches between cases of one process: they call this after touching the environment
+extern "C" void bt_internal_reload_env(void) { g_ft_env.reload(); }
+
 bool bt_internal_ft_grouped(const bt_ft_desc *d) {
     FtPlan p;
     return !ft_validate(d, "ft_grouped") && !ft_plan(d, &p) && p.grouped;
 }
-
-#ifdef BT_EXP_TIMING2
-extern "C" int bt_debug_read2(unsigned long long *out) {
-    BT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(bt_dbg2), sizeof(unsigned long long) * 16));
-    return 0;
-}
-#endif
-#ifdef BT_EXP_TIMING
-extern "C" int bt_debug_read(unsigned long long *out) {
-    BT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(bt_dbg), sizeof(unsigned long long) * 8));
-    unsigned long long z[8] = {0};
-    BT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(bt_dbg), z, sizeof(z)));
-    return 0;
-}
-#endif
 
 extern "C" {
 

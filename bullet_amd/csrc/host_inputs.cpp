@@ -34,8 +34,23 @@ inline bool is_ataxx(const bt_input_desc *d) { return d->kind == BT_INPUT_ATAXX1
 
 inline float sigmoidf_host(float x) { return 1.0f / (1.0f + std::exp(-x)); }  // value.rs:66-68
 
-// returns the number of features written
-inline int map_one(const bt_input_desc *d, const uint8_t *rec, int32_t *stm, int32_t *ntm) {
+// What the reference's mapper panics on (value.rs:80 "Input feature index exceeded input size!", value.rs:91 "More
+// inputs provided than the specified maximum!", the bounds checks of `buckets[ksq]` in chess_buckets.rs:30 and of
+// `targets[result]` in value.rs:101, the u8 underflow of MaterialCount in outputs.rs:29) is reported per record here.
+enum RecError { REC_TOO_MANY = 1, REC_FEATURE = 2, REC_KSQ = 3, REC_RESULT = 4, REC_TOO_FEW = 5 };
+const char *rec_error_text(int code) {
+    switch (code) {
+    case REC_TOO_MANY: return "More inputs provided than the specified maximum!";
+    case REC_FEATURE: return "Input feature index exceeded input size!";
+    case REC_KSQ: return "king square out of range";
+    case REC_RESULT: return "game result out of range";
+    case REC_TOO_FEW: return "fewer than two pieces (output bucket underflows)";
+    default: return "invalid record";
+    }
+}
+
+// returns the number of features written, or -RecError (nothing is ever written past slot nnz - 1)
+inline int map_one(const bt_input_desc *d, const uint8_t *rec, int32_t *stm, int32_t *ntm, int nnz, int num) {
     int cnt = 0;
     if (is_ataxx(d)) {
         AtaxxRecord r;
@@ -44,9 +59,12 @@ inline int map_one(const bt_input_desc *d, const uint8_t *rec, int32_t *stm, int
             for (uint64_t bb = r.bbs[pc]; bb; bb &= bb - 1) {
                 const int sq = __builtin_ctzll(bb);
                 const int s = 49 * pc + sq;
-                if (d->kind == BT_INPUT_ATAXX98 && s >= 98) continue;
+                if (d->kind == BT_INPUT_ATAXX98 && s >= 98) continue;  // ataxx147.rs:52-56
+                const int n = (pc == 2) ? s : 49 * (1 - pc) + sq;
+                if (s >= num || n >= num) return -REC_FEATURE;
+                if (cnt >= nnz) return -REC_TOO_MANY;
                 stm[cnt] = s;
-                ntm[cnt] = (pc == 2) ? s : 49 * (1 - pc) + sq;
+                ntm[cnt] = n;
                 cnt++;
             }
         }
@@ -56,6 +74,7 @@ inline int map_one(const bt_input_desc *d, const uint8_t *rec, int32_t *stm, int
     std::memcpy(&r, rec, 32);
     int s_flip = 0, n_flip = 0, s_base = 0, n_base = 0;
     if (d->kind != BT_INPUT_CHESS768) {
+        if (r.ksq > 63 || r.opp_ksq > 63) return -REC_KSQ;
         s_base = 768 * d->buckets[r.ksq];
         n_base = 768 * d->buckets[r.opp_ksq];
         if (d->kind == BT_INPUT_CHESS_BUCKETS_MIRRORED) {
@@ -63,14 +82,18 @@ inline int map_one(const bt_input_desc *d, const uint8_t *rec, int32_t *stm, int
             n_flip = (r.opp_ksq & 7) > 3 ? 7 : 0;
         }
     }
+    if (__builtin_popcountll(r.occ) > 32) return -REC_TOO_MANY;  // the piece list holds 32 nibbles
     const int shift = d->factorised ? 768 : 0;
     int piece_no = 0;
     for (uint64_t occ = r.occ; occ; occ &= occ - 1, piece_no++) {
         const int sq = __builtin_ctzll(occ);
         const int nib = (r.pcs[piece_no >> 1] >> ((piece_no & 1) * 4)) & 15;
         const int side = nib >> 3, type_off = (nib & 7) << 6;
+        if (type_off >= 384) return -REC_FEATURE;  // piece types 6, 7 do not exist: the index would leave its 768 block
         const int s = s_base + ((side * 384 + type_off + sq) ^ s_flip);
         const int n = n_base + (((1 - side) * 384 + type_off + (sq ^ 56)) ^ n_flip);
+        if (shift + s >= num || shift + n >= num) return -REC_FEATURE;
+        if (cnt + (d->factorised ? 2 : 1) > nnz) return -REC_TOO_MANY;
         stm[cnt] = shift + s;
         ntm[cnt] = shift + n;
         cnt++;
@@ -83,14 +106,35 @@ inline int map_one(const bt_input_desc *d, const uint8_t *rec, int32_t *stm, int
     return cnt;
 }
 
-void map_range(const bt_input_desc *d, const bt_map_opts *o, const uint8_t *records, int lo, int hi, int nnz,
-               int32_t *stm, int32_t *ntm, int32_t *buckets, float *targets, float *weights, std::atomic<int> *bad_blend) {
+// first bad record of a batch: (index << 8) | code, kept as the minimum over the worker threads
+void report_bad(std::atomic<long long> *bad, int index, int code) {
+    const long long v = ((long long)index << 8) | code;
+    long long cur = bad->load();
+    while ((cur < 0 || v < cur) && !bad->compare_exchange_weak(cur, v)) {
+    }
+}
+
+void map_range(const bt_input_desc *d, const bt_map_opts *o, const uint8_t *records, int lo, int hi, int nnz, int num,
+               int32_t *stm, int32_t *ntm, int32_t *buckets, float *targets, float *weights, std::atomic<int> *bad_blend,
+               std::atomic<long long> *bad_record) {
     const float rscale = 1.0f / o->eval_scale;
     const bool ataxx = is_ataxx(d);
     for (int k = lo; k < hi; k++) {
         const uint8_t *rec = records + (size_t)k * 32;
         int32_t *s = stm + (size_t)k * nnz, *n = ntm + (size_t)k * nnz;
-        const int cnt = map_one(d, rec, s, n);
+        const int cnt = map_one(d, rec, s, n, nnz, num);
+        // a bad record is reported (the call fails) and left as an empty list with zero weight
+        auto reject = [&](int code) {
+            report_bad(bad_record, k, code);
+            s[0] = n[0] = -1;
+            buckets[k] = 0, weights[k] = 0.0f;
+            const int tw = o->wdl_output ? 3 : 1;
+            for (int j = 0; j < tw; j++) targets[tw * (size_t)k + j] = 0.0f;
+        };
+        if (cnt < 0) {
+            reject(-cnt);
+            continue;
+        }
         if (cnt < nnz) s[cnt] = n[cnt] = -1;
         int16_t score_i;
         uint8_t result;
@@ -107,7 +151,16 @@ void map_range(const bt_input_desc *d, const bt_map_opts *o, const uint8_t *reco
         int bucket = 0;
         if (o->out_buckets > 1 && !ataxx) {
             const int divisor = (32 + o->out_buckets - 1) / o->out_buckets;
-            bucket = (uint8_t)((uint8_t)__builtin_popcountll(occ) - 2) / (uint8_t)divisor;
+            const int pieces = __builtin_popcountll(occ);
+            if (pieces < 2) {  // outputs.rs:29 computes `popcount - 2` in u8
+                reject(REC_TOO_FEW);
+                continue;
+            }
+            bucket = (uint8_t)((uint8_t)pieces - 2) / (uint8_t)divisor;
+        }
+        if (result > 2) {  // value.rs:101 indexes targets[result]; value.rs:112 would form a target outside [0, 1]
+            reject(REC_RESULT);
+            continue;
         }
         buckets[k] = bucket;
         weights[k] = o->weight_fn ? o->weight_fn(o->fn_user, rec) : 1.0f;  // value.rs:94
@@ -194,26 +247,29 @@ int bt_map_batch(const bt_input_desc *d, const bt_map_opts *o, const void *recor
     BT_REQUIRE(count >= 0, "bt_map_batch: negative count");
     // value.rs:114: assert!((0.0..=1.0).contains(&blend))
     BT_REQUIRE(o->wdl_output || (o->blend >= 0.0f && o->blend <= 1.0f), "WDL proportion must be in [0, 1]");
-    const int nnz = bt_input_max_active(d);
+    const int nnz = bt_input_max_active(d), num = bt_input_num_inputs(d);
     int threads = o->threads < 1 ? 1 : o->threads;
     if (threads > count) threads = count > 0 ? count : 1;
     const uint8_t *rec = static_cast<const uint8_t *>(records);
     std::atomic<int> bad_blend(0);
+    std::atomic<long long> bad_record(-1);
     if (threads == 1) {
-        map_range(d, o, rec, 0, count, nnz, stm, nstm, buckets, targets, weights, &bad_blend);
-        BT_REQUIRE(!bad_blend.load(), "WDL proportion must be in [0, 1]");
-        return BT_OK;
+        map_range(d, o, rec, 0, count, nnz, num, stm, nstm, buckets, targets, weights, &bad_blend, &bad_record);
+    } else {
+        // chunks of ceil(count/threads), model/inputs.rs:88-103
+        const int chunk = (count + threads - 1) / threads;
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; t++) {
+            const int lo = t * chunk, hi = std::min(count, lo + chunk);
+            if (lo >= hi) break;
+            pool.emplace_back(map_range, d, o, rec, lo, hi, nnz, num, stm, nstm, buckets, targets, weights, &bad_blend,
+                              &bad_record);
+        }
+        for (auto &th : pool) th.join();
     }
-    // chunks of ceil(count/threads), model/inputs.rs:88-103
-    const int chunk = (count + threads - 1) / threads;
-    std::vector<std::thread> pool;
-    for (int t = 0; t < threads; t++) {
-        const int lo = t * chunk, hi = std::min(count, lo + chunk);
-        if (lo >= hi) break;
-        pool.emplace_back(map_range, d, o, rec, lo, hi, nnz, stm, nstm, buckets, targets, weights, &bad_blend);
-    }
-    for (auto &th : pool) th.join();
     BT_REQUIRE(!bad_blend.load(), "WDL proportion must be in [0, 1]");
+    const long long bad = bad_record.load();
+    BT_REQUIRE(bad < 0, "bt_map_batch: record %lld: %s", bad >> 8, rec_error_text((int)(bad & 0xff)));
     return BT_OK;
 }
 

@@ -250,9 +250,12 @@ int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bo
         // finishing kernel's own dispatch packet instead of a separate hipEventRecord.
         BT_HIP(hipStreamWaitEvent(s, n->ev_index, 0));
         bt_attach_stop_event(BTK_DENSE_FWD_SMALL, n->ev_fwd);
-        return bt_internal_head_finish(s, &q, n->zpart, bt_internal_ft_head_parts(&f), n->params + n->t_off[3], bk,
-                                       b->targets, n->d.use_entry_weights ? b->entry_weights : nullptr, n->a[0],
-                                       n->grad_y, want_gz0 ? n->gz0 : nullptr, n->loss_partials, &n->n_loss_partials);
+        const int rc = bt_internal_head_finish(s, &q, n->zpart, bt_internal_ft_head_parts(&f), n->params + n->t_off[3], bk,
+                                               b->targets, n->d.use_entry_weights ? b->entry_weights : nullptr, n->a[0],
+                                               n->grad_y, want_gz0 ? n->gz0 : nullptr, n->loss_partials,
+                                               &n->n_loss_partials);
+        if (rc) (void)bt_take_stop_event(BTK_DENSE_FWD_SMALL);  // not launched: do not leave the event armed
+        return rc;
     }
     if (int rc = bt_ft_forward_prebuilt(s, &f, w0, n->params + n->t_off[1], idx, n->hid, n->saved, n->ft_ws,
                                         n->ft_ws_bytes))
@@ -317,6 +320,14 @@ int prepare_next(bt_net *n) {
 const float *net_output(const bt_net *n) { return has_skip(&n->d) ? n->yfin : n->a[n->d.n_dense - 1]; }
 
 }  // namespace
+
+int bt_internal_net_enable_hints(bt_net *n) {
+    if (n->ft_ws_alt) return BT_OK;
+    if (int rc = bt_malloc(&n->ft_ws_alt, n->ft_ws_bytes)) return rc;
+    if (n->perm)
+        if (int rc = bt_malloc(&n->perm_alt, bt_internal_bucket_perm_bytes(n->max_batch, n->d.num_buckets))) return rc;
+    return BT_OK;
+}
 
 extern "C" {
 
@@ -630,17 +641,17 @@ int bt_net_hint_next_batch(bt_net *n, const bt_batch *next, void *ready_event) {
     n->has_next = false;
     if (!next) return BT_OK;
     if (int rc = check_batch(n, next, "bt_net_hint_next_batch")) return rc;
-    if (!n->ft_ws_alt) {  // the second buffer set, on first use
-        if (int rc = bt_malloc(&n->ft_ws_alt, n->ft_ws_bytes)) return rc;
-        if (n->perm)
-            if (int rc = bt_malloc(&n->perm_alt, bt_internal_bucket_perm_bytes(n->max_batch, n->d.num_buckets))) return rc;
-    }
+    // the second buffer set: on the first hint (allocates and waits for the zero fill). bt_train_run asks for it before
+    // its loop starts (bt_internal_net_enable_hints), so that no step of a training run allocates.
+    if (int rc = bt_internal_net_enable_hints(n)) return rc;
     n->next = *next, n->next_ready = reinterpret_cast<hipEvent_t>(ready_event), n->has_next = true;
     return BT_OK;
 }
 
-// save_to_checkpoint, crates/bullet_lib/src/value/save.rs:24-43 (directories are created if missing, errors of the
-// raw / quantised writers are reported but, unlike the reference, also returned)
+// save_to_checkpoint, crates/bullet_lib/src/value/save.rs:24-43 (directories are created if missing). As in the
+// reference (save.rs:34-42) a failing raw.bin / quantised.bin writer -- typically "Failed quantisation from f32 to
+// i16!" on early or unclipped weights -- is printed and does NOT fail the checkpoint: training goes on and
+// optimiser_state/ is complete. bt_last_error() keeps the writer's message. Failures of optimiser_state/ are fatal.
 int bt_net_save_checkpoint(bt_net *n, void *stream, const bt_saved_format *fmt, int n_fmt, const char *dir) {
     BT_REQUIRE(n && dir, "bt_net_save_checkpoint: null argument");
     hipStream_t s = bt_stream(stream);
@@ -663,8 +674,11 @@ int bt_net_save_checkpoint(bt_net *n, void *stream, const bt_saved_format *fmt, 
         BT_HIP(hipStreamSynchronize(s));
         if (int rc = bt_checkpoint_write(&n->d, slow.data(), (opt + "/slow.bin").c_str())) return rc;
     }
-    if (int rc = bt_save_raw(&n->d, host.data(), fmt, n_fmt, (base + "/raw.bin").c_str())) return rc;
-    return bt_save_quantised(&n->d, host.data(), fmt, n_fmt, (base + "/quantised.bin").c_str());
+    if (bt_save_raw(&n->d, host.data(), fmt, n_fmt, (base + "/raw.bin").c_str()))
+        std::printf("Failed to write raw network weights:\n%s\n", bt_last_error());  // save.rs:34-36
+    if (bt_save_quantised(&n->d, host.data(), fmt, n_fmt, (base + "/quantised.bin").c_str()))
+        std::printf("Failed to write quantised network weights:\n%s\n", bt_last_error());  // save.rs:38-42
+    return BT_OK;
 }
 
 // Optimiser::load_from_checkpoint, crates/trainer/src/optimiser.rs:232-236 + adam.rs:309-324

@@ -168,6 +168,7 @@ struct bt_reader {
     size_t mem_pos = 0;
     // set: `mem` is refilled from a decoding source when it runs out (viribinpack shuffle buffers) instead of wrapping
     std::function<int(std::vector<uint8_t> &)> refill;
+    bool clock_seeded = false;  // a shuffling source opened with shuffle_seed = 0: its order differs from process to process
 };
 
 namespace {
@@ -324,6 +325,7 @@ extern "C" int bt_reader_open_viribinpack(const char *const *paths, int n_paths,
         delete r;
         return rc;
     }
+    r->clock_seeded = shuffle_seed == 0;
     *out = r;
     return BT_OK;
 }
@@ -336,6 +338,7 @@ extern "C" int bt_reader_open_sfbinpack(const char *const *paths, int n_paths, s
         delete r;
         return rc;
     }
+    r->clock_seeded = shuffle_seed == 0;
     *out = r;
     return BT_OK;
 }
@@ -454,9 +457,17 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
     const int last_superbatch = cfg->stop_superbatch > 0 ? cfg->stop_superbatch : cfg->end_superbatch;
     const long long total_steps = (long long)(last_superbatch - cfg->start_superbatch + 1) * bps;
 
+    BT_REQUIRE(!(cfg->device_mapper && (cfg->blend_fn || cfg->weight_fn)),
+               "bt_train_run: per-position closures need the host mapper (device_mapper = 0)");
+    const bool dev_map = cfg->device_mapper != 0;
+
     // reader.rs:40: skip batch_size * total_batches(start) records (resume)
     bt_reader *reader = static_cast<bt_reader *>(cfg->reader);  // caller's reader (e.g. a binpack source), kept open
     const bool own_reader = reader == nullptr;
+    // data parallel: the ranks' shards partition ONE global batch only if every rank walks the same record stream
+    BT_REQUIRE(dp_world == 1 || own_reader || !reader->clock_seeded,
+               "bt_train_run: data-parallel training over a shuffling reader needs an explicit shuffle_seed "
+               "(the same on every rank), not 0 = seeded from the clock");
     const uint64_t start_pos = (uint64_t)BG * (uint64_t)bps * (uint64_t)(cfg->start_superbatch - 1);
     if (own_reader) {
         BT_REQUIRE(paths, "bt_train_run: no data files and no reader");
@@ -518,9 +529,6 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
         }                                                                            \
     } while (0)
 
-    BT_REQUIRE(!(cfg->device_mapper && (cfg->blend_fn || cfg->weight_fn)),
-               "bt_train_run: per-position closures need the host mapper (device_mapper = 0)");
-    const bool dev_map = cfg->device_mapper != 0;
     for (auto &s : slots) {
         if (dev_map) {
             TRY(pinned((void **)&s.records, (size_t)B * 32));
@@ -671,6 +679,7 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
     auto sb_timer = clock::now();
     auto secs = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<float>(b - a).count(); };
 
+    TRY(bt_internal_net_enable_hints(net));  // the loop below hints every next batch: allocate its buffer set up front
     int cur_slot = -1, prev_slot = -1;
     TRY(take_ready(&cur_slot));
     TRY(upload(cur_slot, 0));
@@ -704,6 +713,11 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
                                 t, err, sb_positions / t, secs(t_start, clock::now()));
                 if (on_superbatch) on_superbatch(user, p.sb, err, sb_positions / t);
                 running_loss = 0.0f, sb_positions = 0, sb_timer = clock::now();
+                if (dev_map) {  // records the device mapper had to reject (the host mapper fails the batch itself)
+                    int bad = 0;
+                    if (int r2 = bt_map_batch_device_errors(copy_stream, &bad)) return r2;
+                    BT_REQUIRE(bad == 0, "bt_train_run: %d corrupt record(s) in superbatch %d (device mapper)", bad, p.sb);
+                }
             }
         }
         return BT_OK;

@@ -137,7 +137,7 @@ SYMBOLS = [
     "bt_net_destroy", "bt_net_params", "bt_net_grads", "bt_net_momentum", "bt_net_velocity", "bt_net_set_adamw",
     "bt_net_flat_size", "bt_net_max_batch", "bt_net_grads_owned", "bt_chessboard_from_str", "bt_measure_loader_throughput", "bt_reader_open_viribinpack", "bt_reader_open_sfbinpack",
     "bt_net_forward_backward", "bt_net_optimiser_step", "bt_net_forward", "bt_net_hint_next_batch",
-    "bt_input_init", "bt_input_num_inputs", "bt_input_max_active", "bt_map_batch", "bt_map_batch_device",
+    "bt_input_init", "bt_input_num_inputs", "bt_input_max_active", "bt_map_batch", "bt_map_batch_device", "bt_map_batch_device_errors",
     "bt_net_init_weights_host", "bt_lr_at", "bt_wdl_at", "bt_reader_open", "bt_reader_next", "bt_reader_close",
     "bt_train_run",
     "bt_net_tensor_name", "bt_net_tensor_shape", "bt_checkpoint_write", "bt_checkpoint_read", "bt_save_quantised",
@@ -231,6 +231,7 @@ def load():
     L.bt_map_batch.argtypes = [C.POINTER(InputDesc), C.POINTER(MapOpts), C.c_void_p, C.c_int] + [C.c_void_p] * 5
     L.bt_map_batch_device.argtypes = [C.c_void_p, C.POINTER(InputDesc), C.POINTER(MapOpts), C.c_void_p, C.c_int] + \
         [C.c_void_p] * 5
+    L.bt_map_batch_device_errors.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.bt_net_init_weights_host.argtypes = [C.POINTER(NetDesc), C.c_uint64, C.c_int, C.c_void_p]
     L.bt_lr_at.restype = C.c_float
     L.bt_lr_at.argtypes = [C.POINTER(LrSched), C.c_int, C.c_int]

@@ -367,7 +367,8 @@ typedef struct {
 
 /* records: host, count*32 bytes of ChessBoard / AtaxxBoard. Outputs are HOST buffers (pinned
  * recommended): stm,nstm I32[count*nnz]; buckets I32[count]; targets F32[count or 3*count];
- * weights F32[count]. Slots after the -1 terminator are left untouched (value.rs:86-89). */
+ * weights F32[count]. Slots after the -1 terminator are left untouched (value.rs:86-89). Corrupt records are
+ * rejected, never mapped (see bt_map_batch_device_errors below). */
 int bt_map_batch(const bt_input_desc *d, const bt_map_opts *o, const void *records, int count, int32_t *stm,
                  int32_t *nstm, int32_t *buckets, float *targets, float *weights);
 /* SfBinpackLoader (value/loader/sfbinpack.rs:50-225): Stockfish binpack files -> every entry that passes `filter` as
@@ -401,6 +402,13 @@ typedef int (*bt_sf_filter)(void *user, const bt_sf_entry *entry);
 int bt_chessboard_from_str(const char *line, void *record32);
 int bt_map_batch_device(void *stream, const bt_input_desc *d, const bt_map_opts *o, const void *records_dev, int count,
                         int32_t *stm, int32_t *nstm, int32_t *buckets, float *targets, float *weights);
+/* A record the reference's mapper would panic on (more than 32 pieces, piece types 6 / 7, king squares > 63, result
+ * > 2, fewer than two pieces with output buckets: value.rs:80,91,101, chess_buckets.rs:30, outputs.rs:29) makes
+ * bt_map_batch fail with BT_ERR_INVALID ("bt_map_batch: record <i>: <reason>"). The device mapper cannot fail a call
+ * it has only enqueued: it maps such a record to an empty list with zero weight and counts it; this call waits for
+ * `stream`, returns the count since the last call on the current device and clears it. bt_train_run checks it after
+ * every superbatch and fails with BT_ERR_INVALID when it is non-zero. */
+int bt_map_batch_device_errors(void *stream, int *count);
 
 /* ------------------------------------------------------------------------------------------
  * 5. Weight init, schedules, data reader and the superbatch training loop

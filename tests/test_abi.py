@@ -102,3 +102,46 @@ def test_ataxx_mapper_bit_exact_synthetic():
         b = ob.map_batch(ob.input_desc(kind), rec, blend=0.5)
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
+
+
+def _startpos_record():
+    rec = np.zeros(32, dtype=np.uint8)
+    lib.check(lib.load().bt_chessboard_from_str(b"rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1 | 10 | 0.5",
+                                                rec.ctypes.data))
+    return rec
+
+
+@pytest.mark.parametrize("what,reason", [
+    ("too_many", "More inputs provided"), ("piece_type", "Input feature index exceeded"), ("ksq", "king square"),
+    ("result", "game result"), ("too_few", "fewer than two pieces"),
+])
+def test_host_mapper_rejects_corrupt_records(what, reason):
+    """What the reference's mapper panics on (value.rs:80,91,101, chess_buckets.rs:30, outputs.rs:29) fails the call
+    with the index of the first bad record; nothing is written past the record's own slots."""
+    good = _startpos_record()
+    bad = good.copy()
+    kind, layout, kw = "chess768", None, dict(out_buckets=8)
+    if what == "too_many":
+        bad[0:8] = 0xFF  # 64 occupied squares
+    elif what == "piece_type":
+        bad[8] = (bad[8] & 0xF0) | 6  # first piece: type 6 does not exist
+    elif what == "ksq":
+        kind, layout = "chess_buckets", [0] * 64
+        bad[27] = 200
+    elif what == "result":
+        bad[26] = 7
+        kw = dict(out_buckets=8, wdl=True)
+    elif what == "too_few":
+        bad[0:8] = 0
+        bad[0] = 1  # one piece
+    recs = np.concatenate([good, good, bad, good])
+    idesc = lib.make_input_desc(kind, False, layout)
+    nnz = 32
+    guard = 1234567
+    out = (np.full((5, nnz), guard, np.int32), np.full((5, nnz), guard, np.int32), np.full(5, guard, np.int32),
+           np.full(5 * 3, 9.0, np.float32), np.full(5, 9.0, np.float32))
+    with pytest.raises(lib.BtError, match="record 2: " + reason):
+        lib.map_batch(idesc, recs, threads=2, out=out, **kw)
+    assert (out[0][4] == guard).all() and (out[1][4] == guard).all() and out[2][4] == guard  # row past the batch untouched
+    assert out[0][2, 0] == -1 and out[4][2] == 0.0  # the rejected record is an empty list with zero weight
+    lib.map_batch(idesc, np.concatenate([good] * 4), threads=2, out=out, **kw)  # and the good ones still map

@@ -458,6 +458,70 @@ def test_device_mapper_matches_host_mapper(kind, layout, fact, wdl, wrm):
         np.testing.assert_array_max_ulp(host[3], dev[3].cpu().numpy(), maxulp=1)
 
 
+def test_device_mapper_counts_and_neutralises_corrupt_records(tmp_path):
+    """records the host mapper rejects (tests/test_abi.py): the device mapper writes an empty list with zero weight,
+    stays inside the record's slots, and counts them; bt_train_run fails at the end of the superbatch"""
+    rec = np.fromfile(GOLDEN, dtype=np.uint8).reshape(-1, 32)[:512].copy()
+    rec[5, 0:8] = 0xFF                       # 64 pieces
+    rec[9, 8] = (rec[9, 8] & 0xF0) | 7       # piece type 7
+    rec[11, 26] = 9                          # result 9
+    rec[13, 0:8] = 0
+    rec[13, 0] = 1                           # a single piece: the output bucket would underflow
+    bad = [5, 9, 11, 13]
+    idesc = lib.make_input_desc("chess768")
+    n, nnz = rec.shape[0], 32
+    dev = [torch.full((n + 1, nnz), -7, dtype=torch.int32, device="cuda"), torch.full((n + 1, nnz), -7, dtype=torch.int32, device="cuda"),
+           torch.full((n + 1,), -7, dtype=torch.int32, device="cuda"), torch.full((n + 1,), 9.0, device="cuda"),
+           torch.full((n + 1,), 9.0, device="cuda")]
+    drec = gu.dev(rec.reshape(-1))
+    o = lib.MapOpts(8, 0.3, 400.0, 0, 0, 1)
+    cnt = C.c_int(-1)
+    lib.check(L.bt_map_batch_device_errors(gu.stream(), C.byref(cnt)))  # clear what earlier tests may have left
+    lib.check(L.bt_map_batch_device(gu.stream(), C.byref(idesc), C.byref(o), drec.data_ptr(), n, *[t.data_ptr() for t in dev]))
+    lib.check(L.bt_map_batch_device_errors(gu.stream(), C.byref(cnt)))
+    assert cnt.value == len(bad)
+    lib.check(L.bt_map_batch_device_errors(gu.stream(), C.byref(cnt)))
+    assert cnt.value == 0  # reading clears
+    stm, bk, w = dev[0].cpu().numpy(), dev[2].cpu().numpy(), dev[4].cpu().numpy()
+    assert (stm[bad, 0] == -1).all() and (w[bad] == 0).all() and (bk[:n] >= 0).all() and (bk[:n] < 8).all()
+    assert (stm[n] == -7).all() and bk[n] == -7  # nothing written past the batch
+    good = np.setdiff1d(np.arange(n), bad)
+    host = lib.map_batch(idesc, rec[good].reshape(-1).copy(), out_buckets=8, blend=0.3, threads=2)
+    assert np.array_equal(host[2], bk[good]) and np.array_equal(host[0][:, 0], stm[good, 0])
+    # the training loop reports them
+    path = tmp_path / "corrupt.bf"
+    rec.tofile(path)
+    cfg = dict(num_inputs=768, nnz=32, ft_out=32, ft_act="screlu", num_buckets=8, dense=[(1, "identity", True)])
+    net = lib.Net(lib.make_net_desc(**cfg), 256)
+    net.init_weights(seed=3)
+    lr, wdl = lib.LrSched(lib.LR["constant"], 0.001, 0, 0, 0), lib.WdlSched(lib.WDL["constant"], 0.3, 0.3, 0)
+    with pytest.raises(lib.BtError, match="corrupt record"):
+        net.train(idesc, [str(path)], 256, 2, 1, lr, wdl, out_buckets=8, threads=2, device_mapper=True)
+    with pytest.raises(lib.BtError, match="record 5: More inputs"):
+        net.train(idesc, [str(path)], 256, 2, 1, lr, wdl, out_buckets=8, threads=2, device_mapper=False)
+    net.close()
+
+
+def test_checkpoint_survives_a_quantisation_overflow(tmp_path):
+    """save.rs:34-42: a failing raw / quantised writer is printed, the checkpoint (optimiser_state/) is still complete
+    and the call succeeds, so a long run is not aborted by an early weight that does not fit i16"""
+    cfg = dict(num_inputs=768, nnz=32, ft_out=32, ft_act="screlu", dense=[(1, "identity", False)])
+    net = lib.Net(lib.make_net_desc(**cfg), 64)
+    net.init_weights(seed=5)
+    net.tensor(net.params, 0)[3] = 1000.0  # 1000 * 255 does not fit i16
+    fmt = [dict(id="l0w", quant=("i16", 255)), dict(id="l0b", quant=("i16", 255)), dict(id="l1w", quant=("i16", 64)),
+           dict(id="l1b", quant=("i16", 255 * 64))]
+    out = tmp_path / "ckpt"
+    net.save_checkpoint(out, fmt)  # no exception
+    assert b"Failed quantisation from f32 to i16" in L.bt_last_error()
+    assert (out / "optimiser_state" / "weights.bin").exists() and (out / "raw.bin").exists()
+    assert not (out / "quantised.bin").exists()
+    net2 = lib.Net(lib.make_net_desc(**cfg), 64)
+    net2.load_checkpoint(out)
+    assert torch.equal(net2.params, net.params)
+    net.close(), net2.close()
+
+
 def test_train_run_device_mapper_matches_host_mapper():
     """bt_train_run with device_mapper: raw records uploaded, mapped on the copy stream; same run as the host mapper"""
     layout = [0, 0, 1, 1] * 2 + [2] * 8 + [3] * 16

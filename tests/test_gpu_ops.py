@@ -73,9 +73,9 @@ FT_CASES = [
 
 
 @pytest.fixture(params=["auto", "generic"])
-def ft_path(request, monkeypatch):
+def ft_path(request, ft_switches):
     """auto = LDS-resident kernels where the shape allows; generic = the any-shape kernels on every shape"""
-    monkeypatch.setenv("BT_FT_FORCE_GENERIC", "1" if request.param == "generic" else "0")
+    ft_switches(BT_FT_FORCE_GENERIC="1" if request.param == "generic" else "0")
     return request.param
 
 
@@ -134,13 +134,12 @@ SEG_CASES = [
 
 
 @pytest.mark.parametrize("batch,rows,seg,nseg,nnz,act,pairwise,n_inputs,stride,offset,skew", SEG_CASES)
-def test_ft_segment_grouped_vs_oracle(monkeypatch, batch, rows, seg, nseg, nnz, act, pairwise, n_inputs, stride, offset,
+def test_ft_segment_grouped_vs_oracle(ft_switches, batch, rows, seg, nseg, nnz, act, pairwise, n_inputs, stride, offset,
                                       skew):
     """bt_ft_desc.segment: tables too large for LDS processed segment by segment (entry lists + the LDS kernels).
     Same bars as the ungrouped kernels: forward keeps the per-element summation order, backward is a batch sum."""
-    monkeypatch.setenv("BT_FT_FORCE_GROUPED", "1")
-    monkeypatch.setenv("BT_FT_FWD_ITEM", "256")   # several forward / backward items per segment at this batch size
-    monkeypatch.setenv("BT_FT_BWD_CHUNKS", "2")
+    # several forward / backward items per segment at this batch size
+    ft_switches(BT_FT_FORCE_GROUPED=1, BT_FT_FWD_ITEM=256, BT_FT_BWD_CHUNKS=2)
     rng = np.random.default_rng(batch + rows)
     cols = seg * nseg
     out_w = rows // 2 if pairwise else rows
@@ -177,9 +176,9 @@ def test_ft_segment_grouped_vs_oracle(monkeypatch, batch, rows, seg, nseg, nnz, 
     assert np.array_equal(out0, out)  # forward: identical order => identical bits
 
 
-def test_ft_segment_promise_violation_is_loud(monkeypatch):
+def test_ft_segment_promise_violation_is_loud(ft_switches):
     """an index outside its entry's segment: counted on the device and the entry's output turns into NaN"""
-    monkeypatch.setenv("BT_FT_FORCE_GROUPED", "1")
+    ft_switches(BT_FT_FORCE_GROUPED=1)
     rng = np.random.default_rng(5)
     d = lib.FtDesc(batch=300, rows=32, cols=4 * 768, stride=32, offset=0, nnz=32, act=lib.ACT["crelu"], pairwise=0,
                    n_inputs=1, out_ld=32, segment=768)

@@ -48,6 +48,44 @@ int main(int argc, char **argv) {
         uint8_t rec[32];
         bt_chessboard_from_str(line, rec);
     }
-    printf("ok=%d bad=%d\n", ok, bad);
+    // plain bulletformat records (bt_map_batch): random 32-byte records and bit-flipped copies of a valid one, every
+    // input type, output buffers of exactly count * nnz slots (ASan catches a write past them)
+    int rec_ok = 0, rec_bad = 0;
+    {
+        const int layout64[64] = {0};
+        const int layout32[32] = {0};
+        uint8_t valid[32] = {0};
+        bt_chessboard_from_str("rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1 | 10 | 0.5", valid);
+        for (int trial = 0; trial < 40000; trial++) {
+            const int kind = trial % 5, fact = (kind <= 2) ? (trial / 5) % 2 : 0;
+            bt_input_desc d;
+            if (bt_input_init(&d, kind, fact, kind == 1 ? layout64 : kind == 2 ? layout32 : nullptr, kind == 1 ? 64 : kind == 2 ? 32 : 0)) return 2;
+            const int count = 3, nnz = bt_input_max_active(&d);
+            std::vector<uint8_t> recs(32 * count);
+            for (int r = 0; r < count; r++) {
+                if (trial & 8) {
+                    for (int i = 0; i < 32; i++) recs[32 * r + i] = (uint8_t)rng();
+                } else {
+                    memcpy(&recs[32 * r], valid, 32);
+                    for (int i = 0, n = rng() % 4; i < n; i++) recs[32 * r + rng() % 32] ^= (uint8_t)(1u << (rng() % 8));
+                }
+            }
+            bt_map_opts o = {};
+            o.out_buckets = (trial & 16) ? 8 : 1, o.blend = 0.5f, o.eval_scale = 400.0f, o.wdl_output = (trial >> 5) & 1, o.threads = 1 + trial % 3;
+            std::vector<int32_t> stm((size_t)count * nnz), ntm((size_t)count * nnz), bk(count);
+            std::vector<float> tg((size_t)count * 3), w(count);
+            const int rc = bt_map_batch(&d, &o, recs.data(), count, stm.data(), ntm.data(), bk.data(), tg.data(), w.data());
+            (rc ? rec_bad : rec_ok)++;
+            if (!rc) {  // accepted: every listed index and every bucket is in range
+                const int num = bt_input_num_inputs(&d);
+                for (int r = 0; r < count; r++) {
+                    if (bk[r] < 0 || bk[r] >= o.out_buckets) return 3;
+                    for (int i = 0; i < nnz && stm[(size_t)r * nnz + i] >= 0; i++)
+                        if (stm[(size_t)r * nnz + i] >= num || ntm[(size_t)r * nnz + i] < 0 || ntm[(size_t)r * nnz + i] >= num) return 4;
+                }
+            }
+        }
+    }
+    printf("ok=%d bad=%d records ok=%d rejected=%d\n", ok, bad, rec_ok, rec_bad);
     return 0;
 }

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Host-only AddressSanitizer + UBSan run of the data decoders (Stockfish binpack, viriformat, FEN text): valid files
-# written by the tests' encoders are mutated byte-wise 6000 times, plus 20000 random text lines. CPU only.
+# written by the tests' encoders are mutated byte-wise 6000 times, plus 20000 random text lines and 40000 batches of
+# random / bit-flipped plain bulletformat records through bt_map_batch. CPU only.
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p /tmp/bt_fuzz
