@@ -128,10 +128,22 @@ bool bt_internal_ft_grouped(const bt_ft_desc *d);
 // bt_internal_dense_forward_loss
 int bt_internal_head_finish(void *stream, const bt_dense_desc *d, const float *zpart, int nparts, const float *bias,
                             const int32_t *bucket, const float *targets, const float *entry_weights, float *y,
-                            float *grad_y, float *gz_out, float *loss_partials, int *n_loss_partials);
+                            float *grad_y, float *gz_out, float *loss_partials, int *n_loss_partials,
+                            float *gz_parts = nullptr);
+// head: optional. When given (and bt_internal_ft_fused_head_grad_ok), the FT backward also produces the head's own
+// gradients from the activation tile it stages -- dw1, db1 (from gz_parts [n_loss_partials][head_rows], the
+// per-workgroup sums bt_internal_head_finish leaves) and the final loss sum -- and no other kernel has to.
+struct bt_ft_head_grads {
+    float *dw1, *db1;
+    const float *gz_parts, *loss_partials;
+    int n_loss_partials;
+    float *loss_sum;
+};
+bool bt_internal_ft_fused_head_grad_ok(const bt_ft_desc *d, int head_rows);
 int bt_internal_ft_backward_fused(void *stream, const bt_ft_desc *d, const float *gz, const float *w1,
                                   const int32_t *bucket, int head_rows, const float *out, const float *saved, float *dw,
-                                  float *dbias, void *workspace, size_t workspace_bytes);
+                                  float *dbias, void *workspace, size_t workspace_bytes,
+                                  const bt_ft_head_grads *head = nullptr);
 // dense head (out == 1) backward with optional extras: gz_out [B] receives grad_y * f'(y); when loss_partials is
 // given, block (0,0) also sums them in order into loss_sum[0]. light: the small-footprint kernel shape that can share
 // a CU with a resident FT-backward workgroup (only without grad_x / gz_out)

@@ -387,6 +387,7 @@ struct LossArgs {
     const float *targets, *entry_weights;
     float *grad_y, *loss_partials;
     float *gz_out;  // optional: gradient w.r.t. this layer's pre-activation (what the FT backward consumes)
+    float *gz_parts = nullptr;  // optional (head_finish): [workgroups][buckets] sums of gz_out by bucket = dbias partials
 };
 
 template <int NX, bool LOSS>
@@ -464,7 +465,8 @@ __global__ __launch_bounds__(HF_THREADS) void head_finish_kernel(const float *__
                                                                  float *__restrict__ y, bt_dense_desc d, LossArgs la) {
     __shared__ float red[HF_THREADS];
     const int b = blockIdx.x * HF_THREADS + threadIdx.x;
-    float l = 0.0f;
+    float l = 0.0f, gzv = 0.0f;
+    int base_b = -1;
     if (b < d.batch) {
         float z = 0.0f;
         int p = 0;
@@ -487,7 +489,8 @@ __global__ __launch_bounds__(HF_THREADS) void head_finish_kernel(const float *__
         const float dd = g * diff + g * diff;
         const float gy = dd * (sg * (1.0f + (-1.0f * sg)));
         la.grad_y[b] = gy;
-        if (la.gz_out) la.gz_out[b] = gy * bt_act_deriv(d.act, yv);
+        gzv = gy * bt_act_deriv(d.act, yv), base_b = base;
+        if (la.gz_out) la.gz_out[b] = gzv;
     }
     red[threadIdx.x] = l;
     __syncthreads();
@@ -496,6 +499,12 @@ __global__ __launch_bounds__(HF_THREADS) void head_finish_kernel(const float *__
         __syncthreads();
     }
     if (threadIdx.x == 0) la.loss_partials[blockIdx.x] = red[0];
+    if (la.gz_parts) {  // the bias gradient of the head, by bucket (Select backward + batch sum): one wave, fixed tree
+        for (int m = 0; m < d.buckets; m++) {
+            const float s = wave_sum(base_b == m ? gzv : 0.0f);
+            if (threadIdx.x == 0) la.gz_parts[(size_t)blockIdx.x * d.buckets + m] = s;
+        }
+    }
 }
 
 constexpr int DBS_RANGE = 128;  // positions per workgroup in dense_bwd_small
@@ -1615,14 +1624,14 @@ int bt_internal_dense_forward_loss(void *stream, const bt_dense_desc *d, const f
 
 int bt_internal_head_finish(void *stream, const bt_dense_desc *d, const float *zpart, int nparts, const float *bias,
                             const int32_t *bucket, const float *targets, const float *entry_weights, float *y,
-                            float *grad_y, float *gz_out, float *loss_partials, int *n_loss_partials) {
+                            float *grad_y, float *gz_out, float *loss_partials, int *n_loss_partials, float *gz_parts) {
     if (int rc = dense_validate(d, "bt_dense_forward")) return rc;
     BT_REQUIRE(d->out == 1 && zpart && bias && targets && y && grad_y && loss_partials && n_loss_partials,
                "bt_dense_forward(head finish): bad arguments");
     BT_REQUIRE(d->buckets == 1 || bucket, "bt_dense_forward: bucketed layer needs bucket indices");
     const int nwg = bt_div_up(d->batch, HF_THREADS);
     BT_REQUIRE(nwg <= 1024, "bt_dense_forward(head finish): batch too large for the loss-partial buffer");
-    const LossArgs la{targets, entry_weights, grad_y, loss_partials, gz_out};
+    const LossArgs la{targets, entry_weights, grad_y, loss_partials, gz_out, gz_parts};
     BT_LAUNCH(BTK_DENSE_FWD_SMALL, bt_stream(stream), head_finish_kernel, dim3(nwg), dim3(HF_THREADS), 0, zpart, nparts,
               bias, bucket, y, *d, la);
     BT_LAUNCH_CHECK();

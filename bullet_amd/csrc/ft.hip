@@ -34,7 +34,7 @@ __host__ __device__ inline int ft_blk_cap(int nnz, int cols) { return (ft_sorted
 // (bt_internal_reload_env): BT_FT_FORCE_GENERIC=1 runs the any-shape kernels on every shape, BT_FT_FORCE_GROUPED=1
 // the segment-grouped ones wherever a segment is given, BT_FT_FWD_ITEM / BT_FT_BWD_CHUNKS override the item sizes.
 struct FtEnv {
-    bool force_generic = false, force_grouped = false;
+    bool force_generic = false, force_grouped = false, old_bwd = false;
     int fwd_item = 0, bwd_chunks = 0;
     FtEnv() { reload(); }
     void reload() {
@@ -44,6 +44,7 @@ struct FtEnv {
         };
         force_generic = num("BT_FT_FORCE_GENERIC") == 1, force_grouped = num("BT_FT_FORCE_GROUPED") != 0;
         fwd_item = num("BT_FT_FWD_ITEM"), bwd_chunks = num("BT_FT_BWD_CHUNKS");
+        old_bwd = num("BT_FT_OLD_BWD") == 1;  // the range-split reduction (ft_bwd_lds) instead of the octet one
     }
 };
 FtEnv g_ft_env;
@@ -428,6 +429,316 @@ __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t 
     for (int st = IDX_REG; st < nsteps; st++) {
         const int e = e_lo + st * eps + sub;
         place_step(e, (e < e_hi && li < nnz) ? load_j(e) : -1);
+    }
+}
+
+// ------------------------------------------------------------------ index build, "octet" layout (LDS backward)
+// The LDS-resident backward sums every feature's run of a chunk with one 8-lane group; the eight groups of a wave
+// work in lockstep, so the index hands each wave OCTETS: eight runs of (nearly) equal length, sorted by length and
+// dealt to the 16 waves of the backward workgroup in serpentine order (balanced to within one run). A run longer
+// than L = 2^ls blocks of 4 pairs is cut into sub-runs of <= L blocks ("parts") that go to different groups; L is
+// the smallest power of two >= 8 for which a chunk has <= OCT_SLOTS parts. Each wave's work is one contiguous
+// stream of 64-byte rows in the workspace, one uint2 per group:
+//   four u16 byte offsets (entry * 128) of rows of the staged gradient tile, padding = the zero row. The low 7 bits
+//   of an offset are free; in the LAST row of an octet those of the two low halves say where the sum the group has
+//   built goes: x bit 0 = 1, x bits 1-2 = kind (1 = dW tile row `id`: a whole run, 2 = part slot `id`: a sub-run,
+//   0 = nowhere: an empty group of the octet), id = x bits 3-6 | y bits 0-6 << 4
+// plus per chunk the waves' row ranges and the list of cut features {feature, first slot, parts}, which the backward
+// adds up in part order after the chunk. Every dW row has exactly one writer per phase and every sum a fixed order
+// (pairs of a run in ascending entry order, parts in order), so the result does not depend on where a run lands.
+constexpr int OCT_SLOTS = 64;                    // part slots per chunk (LDS: 64 x 128 B)
+constexpr int OCT_FIX = OCT_SLOTS / 2;           // cut features per chunk (each has >= 2 parts)
+constexpr int OCT_WAVES = 16;                    // waves of the backward workgroup
+constexpr int OCT_IDX_THREADS = 512;
+constexpr int OCT_META_BYTES = 64 + OCT_FIX * 8; // u16 wave_start[17], n_fix | uint2 fix[OCT_FIX]
+constexpr uint32_t OCT_PAD2 = ((uint32_t)(FT_CHUNK << 7) << 16) | (uint32_t)(FT_CHUNK << 7);
+__host__ __device__ inline int oct_item_cap(int tc) { return (tc + OCT_SLOTS + 7) & ~7; }
+// rows of a chunk's streams: every octet is at most as long as the sum of its runs
+__host__ __device__ inline int oct_rows_cap(int nnz, int tc) {
+    return (FT_CHUNK * nnz + 3 * (tc + OCT_SLOTS)) / 4 + 4 * OCT_WAVES + 8;
+}
+__host__ __device__ inline size_t oct_index_lds_bytes(int tc) {
+    const int IC = oct_item_cap(tc);
+    return ((size_t)(OCT_IDX_THREADS / 64) * tc + 2 * IC + IC / 8 + 16 + 16 + 64 + 24) * 4 +
+           ((size_t)((tc + 1) & ~1) + 3 * IC + IC / 8 + (size_t)(IC / 64 + 1) * 64) * 2;
+}
+__device__ __forceinline__ int oct_wave_of(int o) {  // serpentine deal of octet o (sorted by length) to the waves
+    const int r = o >> 4, i = o & 15;
+    return (r & 1) ? 15 - i : i;
+}
+
+template <bool GRP>
+__global__ __launch_bounds__(OCT_IDX_THREADS) void ft_index_oct_kernel(const int32_t *__restrict__ idx0,
+                                                                       const int32_t *__restrict__ idx1, int batch, int nnz,
+                                                                       int cols, int chunks_per_input, int fbits,
+                                                                       uint2 *__restrict__ stream,
+                                                                       uint8_t *__restrict__ meta, FtGrp gp,
+                                                                       int cols_total) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    constexpr int T = OCT_IDX_THREADS, NW = T / 64;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int IC = oct_item_cap(cols);
+    uint32_t *cnt = lds;                     // [NW][cols] pairs per (wave, feature) -> within-run start of the wave
+    uint32_t *idest = cnt + NW * cols;       // [IC] dest word of an item (a run or a part of one)
+    uint32_t *itembase = idest + IC;         // [IC] u16 index of the item's first offset in the chunk's stream
+    uint32_t *omax = itembase + IC;          // [IC/8] length of an octet = its longest item
+    uint32_t *tsum = omax + IC / 8;          // [16] scan scratch
+    uint32_t *psum = tsum + 16;              // [16] parts a chunk would have for L = 8 << k
+    uint32_t *keyv = psum + 16;              // [64] items per sort key -> first position of the key
+    uint32_t *wstart = keyv + 64;            // [24] first row of each wave (17), [20] items, [22] cut features
+    uint16_t *item0 = reinterpret_cast<uint16_t *>(wstart + 24);  // [cols] pairs of the feature, then its first item
+    uint16_t *ilen = item0 + ((cols + 1) & ~1);  // [IC] blocks of an item
+    uint16_t *ipos = ilen + IC;              // [IC] item -> position in length order
+    uint16_t *pitem = ipos + IC;             // [IC] position -> item
+    uint16_t *octrow = pitem + IC;           // [IC/8] first row of an octet inside its wave's stream
+    uint16_t *bcnt = octrow + IC / 8;        // [IC/64 + 1][64] items per (64-item block, key)
+
+    const int c = blockIdx.x;
+    int n_e, col0 = 0, start0 = 0;
+    const int32_t *idx = nullptr;
+    if constexpr (GRP) {
+        if (c >= gp.counts[2]) return;
+        const int4 ch = gp.chunks[c];
+        col0 = ch.x * cols, start0 = ch.y, n_e = ch.z;
+    } else {
+        const int k = c / chunks_per_input;
+        const int b0 = (c % chunks_per_input) * FT_CHUNK;
+        n_e = min(FT_CHUNK, batch - b0);
+        idx = (k == 0 ? idx0 : idx1) + (size_t)b0 * nnz;
+    }
+    uint2 *my_stream = stream + (size_t)c * oct_rows_cap(nnz, cols) * 8;
+    uint16_t *my_hdr = reinterpret_cast<uint16_t *>(meta + (size_t)c * OCT_META_BYTES);
+    uint2 *my_fix = reinterpret_cast<uint2 *>(meta + (size_t)c * OCT_META_BYTES + 64);
+
+    for (int i = threadIdx.x; i < NW * cols; i += T) cnt[i] = 0;
+    for (int i = threadIdx.x; i < IC / 8; i += T) omax[i] = 0;
+    for (int i = threadIdx.x; i < (IC / 64 + 1) * 64; i += T) bcnt[i] = 0;
+    if (threadIdx.x < 16) psum[threadIdx.x] = 0;
+    __syncthreads();
+
+    // ---- the index lists of this wave's entries, read once (as ft_index_kernel)
+    int slot = 1;
+    while (slot < nnz) slot <<= 1;
+    const int eps = 64 / slot, sub = lane / slot, li = lane % slot;
+    const int per_wave = (n_e + NW - 1) / NW;
+    const int e_lo = wave * per_wave, e_hi = min(n_e, e_lo + per_wave);
+    constexpr int IDX_REG = 8;  // 512 threads: 32 entries per wave, 2 entries per step at nnz = 32
+    const int nsteps = (per_wave + eps - 1) / eps;
+    auto load_j = [&](int e) -> int {
+        if constexpr (GRP) {
+            const int eid = gp.elist[start0 + e];
+            const int k2 = eid >= batch ? 1 : 0;
+            return (k2 ? idx1 : idx0)[(size_t)(eid - k2 * batch) * nnz + li];
+        } else {
+            return idx[(size_t)e * nnz + li];
+        }
+    };
+    int jr[IDX_REG];
+#pragma unroll
+    for (int st = 0; st < IDX_REG; st++) {
+        const int e = e_lo + st * eps + sub;
+        jr[st] = (st < nsteps && e < e_hi && li < nnz) ? load_j(e) : -1;
+    }
+    const unsigned long long seg = (slot == 64) ? ~0ull : (((1ull << slot) - 1) << (sub * slot));
+    auto n_valid = [&](int e, int j) {  // the first invalid index ends the list (write.rs:231)
+        const bool inval = (e < e_hi) && (li >= nnz || j < 0 || j >= cols_total);
+        const unsigned long long m = __ballot(inval) & seg;
+        return m ? (__ffsll((long long)m) - 1 - sub * slot) : slot;
+    };
+    auto in_seg = [&](int jl) { return !GRP || (jl >= 0 && jl < cols); };
+    auto count_step = [&](int e, int j) {
+        const int nvalid = n_valid(e, j);
+        if (e < e_hi && li < nvalid) {
+            if (in_seg(j - col0)) atomicAdd(&cnt[(size_t)wave * cols + (j - col0)], 1u);
+            else if constexpr (GRP) atomicAdd(gp.viol, 1);
+        }
+    };
+#pragma unroll
+    for (int st = 0; st < IDX_REG; st++)
+        if (st < nsteps) count_step(e_lo + st * eps + sub, jr[st]);
+    for (int st = IDX_REG; st < nsteps; st++) {
+        const int e = e_lo + st * eps + sub;
+        count_step(e, (e < e_hi && li < nnz) ? load_j(e) : -1);
+    }
+    __syncthreads();
+
+    // ---- A: pairs per feature; how many parts would a chunk have for L = 8, 16, ... 4096 blocks?
+    const int per = (cols + T - 1) / T;
+    const int f_lo = min(cols, (int)threadIdx.x * per), f_hi = min(cols, f_lo + per);
+    {
+        uint32_t pc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int f = f_lo; f < f_hi; f++) {
+            uint32_t t = 0;
+            for (int w2 = 0; w2 < NW; w2++) {
+                const uint32_t v = cnt[(size_t)w2 * cols + f];
+                cnt[(size_t)w2 * cols + f] = t;  // pairs of f in the waves before w2: ascending entry order inside a run
+                t += v;
+            }
+            item0[f] = (uint16_t)t;
+            const uint32_t blocks = (t + 3) >> 2;
+#pragma unroll
+            for (int k = 0; k < 10; k++)
+                if (blocks > (8u << k)) pc[k] += (blocks + (8u << k) - 1) >> (3 + k);
+        }
+#pragma unroll
+        for (int k = 0; k < 10; k++)
+            if (pc[k]) atomicAdd(&psum[k], pc[k]);
+    }
+    __syncthreads();
+    int ls = 3;
+    while (ls < 12 && psum[ls - 3] > (uint32_t)OCT_SLOTS) ls++;
+    const uint32_t L = 1u << ls;
+
+    // ---- B: items (whole runs and parts) in feature order; packed scan: items | part slots << 12 | cut features << 20
+    {
+        uint32_t s = 0;
+        for (int f = f_lo; f < f_hi; f++) {
+            const uint32_t blocks = ((uint32_t)item0[f] + 3) >> 2;
+            const uint32_t nsub = blocks ? (blocks + L - 1) >> ls : 0;
+            s += nsub | (nsub > 1 ? (nsub << 12) | (1u << 20) : 0u);
+        }
+        uint32_t incl = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) tsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - s;
+        for (int w2 = 0; w2 < wave; w2++) run += tsum[w2];
+        for (int f = f_lo; f < f_hi; f++) {
+            const uint32_t blocks = ((uint32_t)item0[f] + 3) >> 2;
+            const uint32_t nsub = blocks ? (blocks + L - 1) >> ls : 0;
+            const uint32_t it0 = run & 0xfffu, ps0 = (run >> 12) & 0xffu, fx = run >> 20;
+            item0[f] = (uint16_t)it0;
+            for (uint32_t q = 0; q < nsub; q++) {
+                ilen[it0 + q] = (uint16_t)(q + 1 < nsub ? L : blocks - (nsub - 1) * L);
+                idest[it0 + q] = nsub > 1 ? (2u | ((ps0 + q) << 16)) : (1u | ((uint32_t)f << 16));  // kind | id << 16
+            }
+            if (nsub > 1) my_fix[fx] = make_uint2((uint32_t)f | (ps0 << 16), nsub);
+            run += nsub | (nsub > 1 ? (nsub << 12) | (1u << 20) : 0u);
+        }
+        if (threadIdx.x == T - 1) wstart[20] = run & 0xfffu, wstart[22] = run >> 20;
+    }
+    __syncthreads();
+
+    // ---- C: stable sort of the items by length, longest first (key = min(length, 63))
+    const int n_items = (int)wstart[20];
+    const int nb64 = (n_items + 63) >> 6;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int r_rank[2], r_key[2], r_len[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int blk = wave + j * NW, item = blk * 64 + lane;
+        const bool valid = blk < nb64 && item < n_items;
+        const int len = valid ? (int)ilen[item] : 0, key = min(len, 63);
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 6; bit++) {
+            const unsigned long long bb = __ballot(valid && ((key >> bit) & 1));
+            peers &= ((key >> bit) & 1) ? bb : ~bb;
+        }
+        r_rank[j] = __popcll(peers & lt_mask), r_key[j] = key, r_len[j] = len;
+        if (valid && r_rank[j] == 0) bcnt[blk * 64 + key] = (uint16_t)__popcll(peers);
+    }
+    __syncthreads();
+    if (wave == 0) {  // per key: items in the blocks before each block, then the first position of the key (descending)
+        uint32_t tot = 0;
+        for (int blk = 0; blk < nb64; blk++) {
+            const uint32_t v = bcnt[blk * 64 + lane];
+            bcnt[blk * 64 + lane] = (uint16_t)tot;
+            tot += v;
+        }
+        uint32_t incl = tot;  // sum over keys >= lane
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t dn = __shfl_down(incl, o);
+            if (lane + o < 64) incl += dn;
+        }
+        keyv[lane] = incl - tot;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int blk = wave + j * NW, item = blk * 64 + lane;
+        if (blk < nb64 && item < n_items) {
+            const int pos = (int)keyv[r_key[j]] + (int)bcnt[blk * 64 + r_key[j]] + r_rank[j];
+            ipos[item] = (uint16_t)pos, pitem[pos] = (uint16_t)item;
+            atomicMax(&omax[pos >> 3], (uint32_t)r_len[j]);
+        }
+    }
+    __syncthreads();
+
+    // ---- D: rows of each wave's stream (an octet = as many rows as its longest item), waves rounded up to 4 rows
+    const int n_oct = (n_items + 7) >> 3;
+    if (wave == 0) {
+        uint32_t rows = 0;
+        if (lane < OCT_WAVES)
+            for (int r = 0; r * 16 < n_oct; r++) {
+                const int o = r * 16 + ((r & 1) ? 15 - lane : lane);
+                if (o < n_oct) octrow[o] = (uint16_t)rows, rows += omax[o];
+            }
+        rows = (rows + 3) & ~3u;
+        uint32_t incl = rows;
+#pragma unroll
+        for (int o = 1; o < OCT_WAVES; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (lane < OCT_WAVES) wstart[lane + 1] = incl, my_hdr[lane + 1] = (uint16_t)incl;
+        if (lane == 0) wstart[0] = 0, my_hdr[0] = 0, my_hdr[17] = (uint16_t)wstart[22];
+    }
+    __syncthreads();
+
+    // ---- E: every row starts as padding (offsets of the zero row); where each item's offsets begin
+    {
+        const int R = (int)wstart[OCT_WAVES];
+        uint4 *s4 = reinterpret_cast<uint4 *>(my_stream);
+        for (int i = threadIdx.x; i < R * 4; i += T) s4[i] = make_uint4(OCT_PAD2, OCT_PAD2, OCT_PAD2, OCT_PAD2);
+        for (int item = threadIdx.x; item < n_items; item += T) {
+            const int pos = ipos[item], o = pos >> 3;
+            itembase[item] = ((wstart[oct_wave_of(o)] + octrow[o]) * 8 + (pos & 7)) * 4;
+        }
+    }
+    __syncthreads();  // (orders the padding stores before the stores below: same workgroup, vmcnt drained at the barrier)
+
+    // ---- F: the pairs, each wave its own entries in order (stable inside a run)
+    uint32_t *start = cnt + (size_t)wave * cols;
+    uint16_t *s16 = reinterpret_cast<uint16_t *>(my_stream);
+    const uint32_t in_mask = (4u << ls) - 1;
+    auto place_step = [&](int e, int jraw) {
+        const int nvalid = n_valid(e, jraw);
+        const int j = jraw - col0;
+        const bool active = (e < e_hi) && (li < nvalid) && in_seg(j);
+        unsigned long long peers = __ballot(active);
+        for (int bit = 0; bit < fbits; bit++) {
+            const unsigned long long bb = __ballot(active && ((j >> bit) & 1));
+            peers &= ((j >> bit) & 1) ? bb : ~bb;
+        }
+        if (active) {
+            const int rank = __popcll(peers & lt_mask), count = __popcll(peers);
+            const uint32_t base = start[j], i = base + rank;
+            const uint32_t within = i & in_mask;
+            s16[itembase[item0[j] + (i >> (ls + 2))] + (within >> 2) * 32 + (within & 3)] = (uint16_t)(e << 7);
+            if (rank == count - 1) start[j] = base + count;
+        }
+    };
+#pragma unroll
+    for (int st = 0; st < IDX_REG; st++)
+        if (st < nsteps) place_step(e_lo + st * eps + sub, jr[st]);
+    for (int st = IDX_REG; st < nsteps; st++) {
+        const int e = e_lo + st * eps + sub;
+        place_step(e, (e < e_hi && li < nnz) ? load_j(e) : -1);
+    }
+    __syncthreads();  // the offsets are in place (stores drained): now the control bits of every octet's last row
+    for (int q = threadIdx.x; q < n_oct * 8; q += T) {
+        const int o = q >> 3;
+        const uint32_t row = wstart[oct_wave_of(o)] + octrow[o] + omax[o] - 1;
+        const uint32_t dw = q < n_items ? idest[pitem[q]] : 0u, kind = dw & 3u, id = dw >> 16;
+        unsigned *wp = reinterpret_cast<unsigned *>(my_stream + row * 8 + (q & 7));
+        atomicOr(wp, 1u | (kind << 1) | ((id & 15u) << 3));  // (atomics act on L2, where this workgroup's stores have landed)
+        if (id >> 4) atomicOr(wp + 1, id >> 4);
     }
 }
 
@@ -1190,6 +1501,412 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds_any(const float *__res
                                          chunks_per_input, chunks_per_wg, gp);
 }
 
+#ifdef BT_OCT_TIMING  // developer build (tools/oct_timing.py): cycles per phase of workgroup 0, one row per wave
+__device__ unsigned long long bt_oct_dbg[16 * 8];
+#define OT(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); bt_oct_dbg[(threadIdx.x >> 6) * 8 + (i)] += t_ - t_last; t_last = t_; } } while (0)
+#else
+#define OT(i) do { } while (0)
+#endif
+// Backward over the octet index (ft_index_oct_kernel): same workgroup shape and staging as ft_bwd_lds_body above --
+// dW tile of 32 rows accumulating in LDS, the activated gradient tile of a chunk staged once -- but the reduction
+// walks per-wave streams: each 8-lane group sums ONE run (or part of a long run) at a time, the eight groups of a
+// wave finish their runs in the same row, and a finished sum is added to its dW row (or parked in its part slot)
+// by one full-wave read-modify-write per eight runs. Parts of cut runs are added to the dW tile in part order after
+// the chunk's barrier. The stream rows come straight from global memory through a register ring two 4-row sets
+// deep; the first two sets of a chunk are peeled so that their waits do not cover the next chunk's staging loads
+// (vmcnt counts in order), which are issued right behind them.
+//
+// HDW (needs FUSED, no PAIR / GRP; every chunk of a workgroup belongs to one input): the head's own weight gradient
+// dW1[bucket[b]][col] += gz[b] * out[b][col] (Matmul::backward dW = dY X^T with one selected row per position,
+// matmul.rs:99-126 + SelectPad, select.rs:93-110) is formed from the `out` tile this kernel stages anyway, so no
+// other kernel re-reads the [B][2H] activations: per staging pass a wave holds 8 entries x 32 columns, exactly the
+// B fragment of v_mfma_f32_16x16x4_f32 (k = entry pair, n = half * 8 + float4 slot); A is the one-hot of the bucket
+// (rows = buckets), the two entries sharing a k take turns through a zeroed half, and the 16 x 16 f32 accumulators
+// (one per float4 component) run through all chunks of the workgroup: an exact-f32 fma chain in a fixed order.
+typedef float oct_f32x4 __attribute__((ext_vector_type(4)));
+struct FtHeadGradSink {
+    float *pw1;         // [G][n_inputs * out_w * w1_rows] per-chunk-group partials of dW1 (column-major like w1)
+    size_t pw1_stride;  // floats per chunk group
+};
+
+template <bool PAIR, bool FUSED, bool GRP, bool HDW>
+__device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_out, const FtFusedSrc &fs,
+                                                const float *__restrict__ out, const float *__restrict__ saved,
+                                                const uint2 *__restrict__ stream, const uint8_t *__restrict__ meta,
+                                                float *__restrict__ partial_w, float *__restrict__ partial_b,
+                                                const bt_ft_desc &d, int ntiles, int chunks_per_input, int chunks_per_wg,
+                                                const FtGrp &gp, int rows_cap, const FtHeadGradSink &hg) {
+    static_assert(!HDW || (FUSED && !PAIR && !GRP), "HDW: fused single-output head over an ungrouped, unpaired table");
+    extern __shared__ __align__(16) float lds_f[];
+    const int tc = GRP ? gp.tile_cols : d.cols;
+    float *acc = lds_f;                                 // [tc][32]
+    float *gt = acc + (size_t)tc * LDS_RT;              // [FT_CHUNK + 1][32], last row = zeros (padding target)
+    float *parts = gt + (FT_CHUNK + 1) * LDS_RT;        // [OCT_SLOTS][32] sums of the parts of cut runs
+    float *w1t = parts + OCT_SLOTS * LDS_RT;            // FUSED: [n_inputs][w1_rows][TW]
+    const int rt = blockIdx.x % ntiles, cg = blockIdx.x / ntiles;
+    const int half_rows = d.rows / 2;
+    const int nchunks = d.n_inputs * chunks_per_input;
+    int g_clo = 0, g_chi = 0;
+    if constexpr (GRP) {
+        if (cg >= gp.counts[1]) return;
+        const int4 it = gp.items[cg];
+        g_clo = it.y, g_chi = it.y + it.z;
+    }
+    const int out_w = PAIR ? half_rows : d.rows;
+    constexpr int TW = PAIR ? 16 : 32;
+
+    if constexpr (FUSED) {
+        for (int q = threadIdx.x; q < d.n_inputs * fs.w1_rows * TW; q += LDS_THREADS) {
+            const int c = q % TW, bk = (q / TW) % fs.w1_rows, k = q / (TW * fs.w1_rows);
+            w1t[q] = fs.w1[(size_t)(k * out_w + rt * TW + c) * fs.w1_rows + bk];
+        }
+    }
+    for (int q = threadIdx.x; q < tc * LDS_RT; q += LDS_THREADS) acc[q] = 0.0f;
+    if (threadIdx.x < LDS_RT) gt[FT_CHUNK * LDS_RT + threadIdx.x] = 0.0f;
+
+    const int s8 = threadIdx.x & 7, el0 = threadIdx.x >> 3;  // staging role: 128 entries x 8 float4 per pass
+    int rg_e, rg_s;                                           // reduce role: group rg_e of the wave, float4 rg_s of the row
+    fwd_gather_slot(threadIdx.x & 63, rg_e, rg_s);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wv * 8 + rg_e;
+    float4 bsum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int c_lo = GRP ? g_clo : cg * chunks_per_wg, c_hi = GRP ? g_chi : min(nchunks, c_lo + chunks_per_wg);
+    constexpr int NPASS = FT_CHUNK / 128;
+    float4 r_go[NPASS], r_a[NPASS], r_b[NPASS];
+    int r_eid[NPASS], r_ne = 0;
+    uint32_t p_r0 = 0, p_r1 = 0, p_nfix = 0;  // the prefetched chunk's row range of this wave, its cut features
+    uint2 p_fix = make_uint2(0u, 0u);
+    oct_f32x4 hd[4];                          // HDW: dW1 accumulators [bucket rows 4 * (lane / 16) ..][column lane % 16]
+#pragma unroll
+    for (int i = 0; i < 4; i++) hd[i] = oct_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const uint32_t t_col = PAIR ? rt * 16 + (s8 & 3) * 4 : rt * LDS_RT + s8 * 4;
+    auto load_eids = [&](int c) {
+        if constexpr (GRP) {
+            const int4 ch = gp.chunks[min(c, c_hi - 1)];
+#pragma unroll
+            for (int pass = 0; pass < NPASS; pass++) r_eid[pass] = gp.elist[ch.y + min(el0 + pass * 128, ch.z - 1)];
+        }
+    };
+    // All loads of a prefetch are unconditional (rows past the chunk's end re-read its last entry and are dropped when
+    // the tile is staged): their number is then known to the compiler, and the stream waits in front of them stay exact.
+    auto prefetch = [&](int c) {
+        if constexpr (GRP) {
+            r_ne = gp.chunks[c].z;
+#pragma unroll
+            for (int pass = 0; pass < NPASS; pass++) {
+                const int e = r_eid[pass];
+                const int k = e >= d.batch ? 1 : 0, b = e - k * d.batch;
+                const size_t o_out = (size_t)b * d.out_ld + (size_t)k * out_w + t_col;
+                r_go[pass] = r_a[pass] = r_b[pass] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if constexpr (FUSED) {
+                    r_go[pass].x = fs.gz[b];
+                    r_go[pass].y = __int_as_float(fs.bucket ? fs.bucket[b] : 0);
+                    r_go[pass].z = __int_as_float(k);
+                } else {
+                    r_go[pass] = *reinterpret_cast<const float4 *>(grad_out + o_out);
+                }
+                if constexpr (PAIR) {
+                    const float *sv = saved + (size_t)e * d.rows + rt * 16 + (s8 & 3) * 4;
+                    r_a[pass] = *reinterpret_cast<const float4 *>(sv);
+                    r_b[pass] = *reinterpret_cast<const float4 *>(sv + half_rows);
+                } else {
+                    r_a[pass] = *reinterpret_cast<const float4 *>(out + o_out);
+                }
+            }
+            load_eids(c + 1);
+        } else {
+            // wave-uniform chunk base (SGPRs) + 32-bit per-lane element offsets
+            const int kc = c / chunks_per_input, b0 = (c % chunks_per_input) * FT_CHUNK;
+            const int n_e = min(FT_CHUNK, d.batch - b0);
+            r_ne = n_e;
+            const float *go_base = grad_out + (size_t)b0 * d.out_ld + (size_t)kc * out_w;
+            const float *out_base = out + (size_t)b0 * d.out_ld + (size_t)kc * out_w;
+            const float *sav_base = saved + ((size_t)kc * d.batch + b0) * d.rows;
+#pragma unroll
+            for (int pass = 0; pass < NPASS; pass++) {
+                const uint32_t el = (uint32_t)min(el0 + pass * 128, n_e - 1);
+                const uint32_t o_out = el * (uint32_t)d.out_ld + t_col;
+                r_go[pass] = r_a[pass] = r_b[pass] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if constexpr (FUSED) {
+                    r_go[pass].x = fs.gz[b0 + el];
+                    r_go[pass].y = __int_as_float(fs.bucket ? fs.bucket[b0 + el] : 0);
+                } else {
+                    r_go[pass] = *reinterpret_cast<const float4 *>(go_base + o_out);
+                }
+                if constexpr (PAIR) {
+                    const float *sv = sav_base + el * (uint32_t)d.rows + rt * 16 + (s8 & 3) * 4;
+                    r_a[pass] = *reinterpret_cast<const float4 *>(sv);
+                    r_b[pass] = *reinterpret_cast<const float4 *>(sv + half_rows);
+                } else {
+                    r_a[pass] = *reinterpret_cast<const float4 *>(out_base + o_out);
+                }
+            }
+        }
+        const uint16_t *hdr = reinterpret_cast<const uint16_t *>(meta + (size_t)c * OCT_META_BYTES);
+        p_r0 = hdr[wv], p_r1 = hdr[wv + 1], p_nfix = hdr[17];
+        p_fix = reinterpret_cast<const uint2 *>(meta + (size_t)c * OCT_META_BYTES + 64)[min(grp, OCT_FIX - 1)];
+    };
+    // parts of the cut runs of the chunk just reduced -> dW tile, in part order (one group per cut feature)
+    auto fixup = [&](const uint2 fx, uint32_t nfix) {
+        if ((uint32_t)grp < nfix) {
+            const uint32_t f = fx.x & 0xffffu, s0 = fx.x >> 16, np = fx.y;
+            float4 s = *reinterpret_cast<const float4 *>(parts + s0 * LDS_RT + rg_s * 4);
+            for (uint32_t j = 1; j < np; j++) add4(s, *reinterpret_cast<const float4 *>(parts + (s0 + j) * LDS_RT + rg_s * 4));
+            float4 *dst = reinterpret_cast<float4 *>(acc + f * LDS_RT + rg_s * 4);
+            float4 cur = *dst;
+            add4(cur, s);
+            *dst = cur;
+        }
+    };
+    if (c_lo < c_hi) {
+        load_eids(c_lo);
+        prefetch(c_lo);
+    }
+    uint2 cur_fix = make_uint2(0u, 0u);
+    uint32_t cur_nfix = 0;
+#ifdef BT_OCT_TIMING
+    unsigned long long t_last = __builtin_readcyclecounter();
+#endif
+    OT(0);
+    for (int c = c_lo; c < c_hi; c++) {
+        const int kc = GRP ? 0 : c / chunks_per_input;
+        const int n_e = r_ne;
+        OT(1);
+        __syncthreads();  // the previous chunk's readers are done with gt; its parts are complete
+        OT(2);
+        // this wave's stream of the chunk: rows [r0, r0 + n), n a multiple of 4; the first two 4-row sets now
+        const int r0 = __builtin_amdgcn_readfirstlane((int)p_r0), n = __builtin_amdgcn_readfirstlane((int)p_r1) - r0;
+        const uint2 *sp = stream + ((size_t)c * rows_cap + r0) * 8 + rg_e;
+        const int t1 = min(4, max(n - 4, 0));
+        uint2 qa0 = sp[0], qa1 = sp[8], qa2 = sp[16], qa3 = sp[24];
+        uint2 qb0 = sp[(t1 + 0) * 8], qb1 = sp[(t1 + 1) * 8], qb2 = sp[(t1 + 2) * 8], qb3 = sp[(t1 + 3) * 8];
+        fixup(cur_fix, cur_nfix);
+        cur_fix = p_fix, cur_nfix = __builtin_amdgcn_readfirstlane((int)p_nfix);
+#pragma unroll
+        for (int pass = 0; pass < NPASS; pass++) {
+            const int el = el0 + pass * 128;
+            if constexpr (HDW) {
+                // (whole wave: MFMA runs on all lanes; entries past the chunk's end count with gz = 0)
+                const float gzv = el < n_e ? r_go[pass].x : 0.0f;
+                const int bk = __float_as_int(r_go[pass].y);
+                const float4 o = r_a[pass];
+                const bool odd = (threadIdx.x >> 3) & 1;
+                const float4 pe = odd ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(gzv * o.x, gzv * o.y, gzv * o.z, gzv * o.w);
+                const float4 po = odd ? make_float4(gzv * o.x, gzv * o.y, gzv * o.z, gzv * o.w) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                const int m = threadIdx.x & 15;
+                const float a_e = row_share<0>(bk) == m ? 1.0f : 0.0f, a_o = row_share<8>(bk) == m ? 1.0f : 0.0f;
+                hd[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_e, pe.x, hd[0], 0, 0, 0);
+                hd[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_e, pe.y, hd[1], 0, 0, 0);
+                hd[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_e, pe.z, hd[2], 0, 0, 0);
+                hd[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_e, pe.w, hd[3], 0, 0, 0);
+                hd[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, po.x, hd[0], 0, 0, 0);
+                hd[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, po.y, hd[1], 0, 0, 0);
+                hd[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, po.z, hd[2], 0, 0, 0);
+                hd[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, po.w, hd[3], 0, 0, 0);
+            }
+            if (el < n_e) {
+                float4 go = r_go[pass];
+                if constexpr (FUSED) {
+                    const float gzv = go.x;
+                    const int bk = __float_as_int(go.y);
+                    const int ke = GRP ? __float_as_int(go.z) : kc;
+                    const float4 wv4 = *reinterpret_cast<const float4 *>(
+                        w1t + (ke * fs.w1_rows + bk) * TW + (PAIR ? (s8 & 3) : s8) * 4);
+                    go = make_float4(gzv * wv4.x, gzv * wv4.y, gzv * wv4.z, gzv * wv4.w);
+                }
+                float4 g;
+                if constexpr (PAIR) {
+                    const float4 own = (s8 < 4) ? r_a[pass] : r_b[pass], oth = (s8 < 4) ? r_b[pass] : r_a[pass];
+                    const float4 dv = bt_act_deriv4(d.act, own);
+                    g = make_float4((go.x * oth.x) * dv.x, (go.y * oth.y) * dv.y, (go.z * oth.z) * dv.z,
+                                    (go.w * oth.w) * dv.w);
+                } else {
+                    const float4 dv = bt_act_deriv4(d.act, r_a[pass]);
+                    g = make_float4(go.x * dv.x, go.y * dv.y, go.z * dv.z, go.w * dv.w);
+                }
+                *reinterpret_cast<float4 *>(gt + el * LDS_RT + s8 * 4) = g;
+                bsum.x += g.x, bsum.y += g.y, bsum.z += g.z, bsum.w += g.w;
+            }
+        }
+        OT(3);
+        __syncthreads();
+        OT(4);
+        prefetch(min(c + 1, c_hi - 1));  // (the last chunk fetches itself again: unconditional on purpose, see above)
+        OT(5);
+
+        float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const char *gb = reinterpret_cast<const char *>(gt) + rg_s * 16;
+        auto row = [&](const uint2 q) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(gb + (q.x & 0xff80u));
+            const float4 v1 = *reinterpret_cast<const float4 *>(gb + (q.x >> 16));
+            const float4 v2 = *reinterpret_cast<const float4 *>(gb + (q.y & 0xff80u));
+            const float4 v3 = *reinterpret_cast<const float4 *>(gb + (q.y >> 16));
+            add4(a, v0), add4(a, v1), add4(a, v2), add4(a, v3);
+            if (__builtin_amdgcn_readfirstlane((int)q.x) & 1) {  // last row of an octet: the whole wave ends its runs here
+                const uint32_t kind = (q.x >> 1) & 3u, id = ((q.x >> 3) & 15u) | ((q.y & 127u) << 4);
+                if (kind == 1u) {
+                    float4 *dst = reinterpret_cast<float4 *>(acc + id * LDS_RT + rg_s * 4);
+                    float4 cur = *dst;
+                    add4(cur, a);
+                    *dst = cur;
+                } else if (kind == 2u) {
+                    *reinterpret_cast<float4 *>(parts + id * LDS_RT + rg_s * 4) = a;
+                }
+                a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        };
+        // rows t .. t+3 of the stream (clamped to its last set: a short stream re-reads rows it never uses)
+        auto fetch = [&](int t, uint2 &x0, uint2 &x1, uint2 &x2, uint2 &x3) {
+            const int tt = min(t, max(n - 4, 0));
+            x0 = sp[(tt + 0) * 8], x1 = sp[(tt + 1) * 8], x2 = sp[(tt + 2) * 8], x3 = sp[(tt + 3) * 8];
+        };
+        // peeled: sets 0 and 1 were fetched before the staging loads of the next chunk
+        if (0 < n) row(qa0), row(qa1), row(qa2), row(qa3);
+        fetch(8, qa0, qa1, qa2, qa3);
+        if (4 < n) row(qb0), row(qb1), row(qb2), row(qb3);
+        fetch(12, qb0, qb1, qb2, qb3);
+        for (int t = 8; t < n; t += 8) {
+            row(qa0), row(qa1), row(qa2), row(qa3);
+            fetch(t + 8, qa0, qa1, qa2, qa3);
+            if (t + 4 < n) row(qb0), row(qb1), row(qb2), row(qb3);
+            fetch(t + 12, qb0, qb1, qb2, qb3);
+        }
+        OT(6);
+    }
+    __syncthreads();
+    OT(7);
+    fixup(cur_fix, cur_nfix);
+    __syncthreads();
+    float *pw = partial_w + (size_t)cg * tc * d.stride;
+    for (int q = threadIdx.x; q < tc * 8; q += LDS_THREADS) {
+        const int f = q >> 3, t8 = q & 7;
+        *reinterpret_cast<float4 *>(pw + (size_t)f * d.stride + d.offset + tile_row(PAIR, rt, half_rows, t8 * 4)) =
+            *reinterpret_cast<const float4 *>(acc + f * LDS_RT + t8 * 4);
+    }
+    // bias partial: fixed-order sum over the 128 staging thread groups, in two levels (8 x 16)
+    *reinterpret_cast<float4 *>(gt + el0 * LDS_RT + s8 * 4) = bsum;
+    __syncthreads();
+    float bpart = 0.0f;
+    if (threadIdx.x < 8 * LDS_RT) {
+        const int col = threadIdx.x & (LDS_RT - 1), part = threadIdx.x / LDS_RT;
+        for (int i = 0; i < 16; i++) bpart += gt[(part * 16 + i) * LDS_RT + col];
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 * LDS_RT) gt[threadIdx.x] = bpart;
+    __syncthreads();
+    if (threadIdx.x < LDS_RT) {
+        float s = 0.0f;
+        for (int i = 0; i < 8; i++) s += gt[i * LDS_RT + threadIdx.x];
+        partial_b[(size_t)cg * d.rows + tile_row(PAIR, rt, half_rows, threadIdx.x)] = s;
+    }
+    if constexpr (HDW) {
+        // the waves' dW1 accumulators -> one partial per (bucket, column) of this tile, waves and halves in order.
+        // The dW tile has been written out (barriers above), so its LDS holds the 16 x w1_rows x 64 floats.
+        float *tmp = acc;
+        const int lane = threadIdx.x & 63, qd = lane >> 4, j = lane & 15;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int m = 4 * qd + r;
+            if (m < fs.w1_rows) {
+                float *t2 = tmp + (((size_t)wv * fs.w1_rows + m) * 2 + (j >> 3)) * 32 + 4 * (j & 7);
+                t2[0] = hd[0][r], t2[1] = hd[1][r], t2[2] = hd[2][r], t2[3] = hd[3][r];
+            }
+        }
+        __syncthreads();
+        const int kk = c_lo / chunks_per_input;  // the one input all chunks of this workgroup belong to (host-checked)
+        for (int q = threadIdx.x; q < fs.w1_rows * 32; q += LDS_THREADS) {
+            const int m = q >> 5, col = q & 31;
+            float s = 0.0f;
+            for (int w2 = 0; w2 < OCT_WAVES; w2++) {
+                s += tmp[(((size_t)w2 * fs.w1_rows + m) * 2 + 0) * 32 + col];
+                s += tmp[(((size_t)w2 * fs.w1_rows + m) * 2 + 1) * 32 + col];
+            }
+            hg.pw1[(size_t)cg * hg.pw1_stride + (size_t)(kk * out_w + rt * 32 + col) * fs.w1_rows + m] = s;
+        }
+    }
+}
+
+template <bool PAIR, bool FUSED, bool GRP, bool HDW>
+__global__ __launch_bounds__(LDS_THREADS) void ft_bwd_oct(const float *__restrict__ grad_out, FtFusedSrc fs,
+                                                          const float *__restrict__ out, const float *__restrict__ saved,
+                                                          const uint2 *__restrict__ stream,
+                                                          const uint8_t *__restrict__ meta, float *__restrict__ partial_w,
+                                                          float *__restrict__ partial_b, bt_ft_desc d, int ntiles,
+                                                          int chunks_per_input, int chunks_per_wg, FtGrp gp, int rows_cap,
+                                                          FtHeadGradSink hg) {
+    ft_bwd_oct_body<PAIR, FUSED, GRP, HDW>(grad_out, fs, out, saved, stream, meta, partial_w, partial_b, d, ntiles,
+                                           chunks_per_input, chunks_per_wg, gp, rows_cap, hg);
+}
+
+// Merge of the fused-head backward: the dW tile and bias as ft_bwd_merge, plus the head's gradients that used to
+// come from a kernel of their own: dW1 = sum of the chunk groups' partials (the groups of input k, in order), the
+// head bias gradient db1[m] = sum over positions with bucket m of gz and the loss sum, both from the per-workgroup
+// partials the head's finishing kernel left, in order.
+struct FtHeadMerge {
+    const float *pw1;
+    size_t pw1_stride;
+    float *dw1, *db1;
+    const float *gz_parts;  // [n_loss_partials][w1_rows] sums of gz by bucket, one row per workgroup of the head finish
+    const float *loss_partials;
+    int n_loss_partials;
+    float *loss_sum;
+    int w1_rows, groups_per_input, n1;  // n1 = n_inputs * out_w * w1_rows floats of dW1
+};
+__global__ __launch_bounds__(256) void ft_bwd_merge_head(const float *__restrict__ partial_w,
+                                                         const float *__restrict__ partial_b, float *__restrict__ dw,
+                                                         float *__restrict__ dbias, bt_ft_desc d, int G, FtHeadMerge hm,
+                                                         int blocks_w) {
+    const int rows4 = d.rows / 4;
+    if ((int)blockIdx.x < blocks_w) {
+        const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        const long long nw = (long long)d.cols * rows4;
+        if (t < nw) {
+            const int f = (int)(t / rows4), r = (int)(t % rows4) * 4;
+            const size_t o = (size_t)f * d.stride + d.offset + r;
+            float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (int g = 0; g < G; g++) {
+                const float4 v = *reinterpret_cast<const float4 *>(partial_w + (size_t)g * d.cols * d.stride + o);
+                s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+            }
+            *reinterpret_cast<float4 *>(dw + o) = s;
+        } else if (dbias && t < nw + d.rows) {
+            const int r = (int)(t - nw);
+            float s = 0.0f;
+            for (int g = 0; g < G; g++) s += partial_b[(size_t)g * d.rows + r];
+            dbias[r] = s;
+        }
+        return;
+    }
+    const int hb = blockIdx.x - blocks_w;  // head blocks: dW1 elements, then one block for db1 and the loss
+    const int blocks_1 = (hm.n1 + 255) / 256;
+    if (hb < blocks_1) {
+        const int e = hb * 256 + threadIdx.x;
+        if (e < hm.n1) {
+            const int k = e / (hm.n1 / d.n_inputs);
+            float s = 0.0f;
+            for (int g = k * hm.groups_per_input; g < (k + 1) * hm.groups_per_input; g++) s += hm.pw1[(size_t)g * hm.pw1_stride + e];
+            hm.dw1[e] = s;
+        }
+        return;
+    }
+    // last block: the loss sum and db1[m] from the finishing kernel's per-workgroup partials -- thread t takes
+    // partials t, t + 256, ... in order, then a fixed tree over the threads
+    __shared__ float red[256];
+    for (int m = -1; m < hm.w1_rows; m++) {  // m = -1: the loss
+        float s = 0.0f;
+        for (int i = threadIdx.x; i < hm.n_loss_partials; i += 256)
+            s += m < 0 ? hm.loss_partials[i] : hm.gz_parts[(size_t)i * hm.w1_rows + m];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) (m < 0 ? hm.loss_sum : hm.db1 + m)[0] = red[0];
+        __syncthreads();
+    }
+}
+
 // segment-grouped merge: dw[seg*tc + f] = sum over the segment's backward items of their slabs (item order = list
 // order, fixed); a segment without entries gets zeros; dbias = sum over all items
 __global__ __launch_bounds__(256) void ft_bwd_merge_grp(const float *__restrict__ partial_w,
@@ -1257,6 +1974,13 @@ struct FtPlan {
     bool grouped;
     int tc, nseg, grp_blocks, max_chunks, max_fitems, max_bitems, fwd_item, g_ch;
     size_t off_segof, off_blkcnt, off_elist, off_chunks, off_fitems, off_bitems, off_counts, off_segitems;
+    // octet index of the LDS backward (ft_index_oct_kernel / ft_bwd_oct)
+    bool oct;
+    int rows_cap;
+    size_t off_stream, off_meta, lds_oct_bytes;
+    // head weight gradient formed inside the fused backward (ft_bwd_oct<HDW>): per-chunk-group partials of dW1
+    bool hdw;
+    size_t off_pw1, pw1_stride;
 };
 
 int ft_validate(const bt_ft_desc *d, const char *who) {
@@ -1365,6 +2089,20 @@ int ft_plan(const bt_ft_desc *d, FtPlan *p) {
         p->off_pb = o;
         o += bt_align((size_t)p->G * d->rows * sizeof(float));
     }
+    p->rows_cap = oct_rows_cap(d->nnz, p->tc);
+    p->lds_oct_bytes = ((size_t)p->tc * LDS_RT + (FT_CHUNK + 1) * LDS_RT + OCT_SLOTS * LDS_RT) * sizeof(float);
+    p->oct = p->lds_path && !g_ft_env.old_bwd && oct_item_cap(p->tc) <= 1024 && p->rows_cap < 65536 &&
+             oct_index_lds_bytes(p->tc) <= 150 * 1024;
+    p->off_stream = p->off_meta = p->off_pw1 = 0;
+    if (p->oct) {
+        p->off_stream = o, o += bt_align((size_t)p->nchunks * p->rows_cap * 8 * sizeof(uint2));
+        p->off_meta = o, o += bt_align((size_t)p->nchunks * OCT_META_BYTES);
+    }
+    // (every chunk of a workgroup must belong to one input; the waves' accumulators are merged through the dW tile's LDS)
+    p->pw1_stride = (size_t)d->n_inputs * d->rows * FtPlan::kFusedMaxRows;
+    p->hdw = p->oct && !p->grouped && !d->pairwise && p->chunks_per_input % p->chunks_per_wg == 0 &&
+             (size_t)p->tc * LDS_RT >= (size_t)OCT_WAVES * FtPlan::kFusedMaxRows * 64;
+    if (p->hdw) p->off_pw1 = o, o += bt_align((size_t)p->G * p->pw1_stride * sizeof(float));
     p->total = o;
     return BT_OK;
 }
@@ -1387,14 +2125,44 @@ FtGrp ft_grp(const FtPlan &p, char *ws, bool fwd) {
 
 int ft_backward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, const float *grad_out, FtFusedSrc fs,
                            const float *out, const float *saved, const uint16_t *sorted, const uint32_t *offs, char *ws,
-                           float *dw, float *dbias) {
+                           float *dw, float *dbias, const bt_ft_head_grads *head = nullptr) {
     float *pw = reinterpret_cast<float *>(ws + p.off_pw), *pb = reinterpret_cast<float *>(ws + p.off_pb);
     dim3 grid(p.ntiles * p.G), block(LDS_THREADS);
     const bool fused = fs.gz != nullptr;
-    const size_t lds = p.lds_bwd_bytes + (fused ? (size_t)d->n_inputs * fs.w1_rows * 32 * sizeof(float) : 0);
+    const size_t lds = (p.oct ? p.lds_oct_bytes : p.lds_bwd_bytes) +
+                       (fused ? (size_t)d->n_inputs * fs.w1_rows * 32 * sizeof(float) : 0);
     const bool lean = !p.grouped && !d->pairwise && ft_sorted_cap(d->nnz, d->cols) / 8 <= 2 * LDS_THREADS;
     const FtGrp gp = ft_grp(p, ws, false);
     const int cpi = p.grouped ? 1 : p.chunks_per_input;
+    if (p.oct) {
+        const uint2 *stream = reinterpret_cast<const uint2 *>(ws + p.off_stream);
+        const uint8_t *meta = reinterpret_cast<const uint8_t *>(ws + p.off_meta);
+        const FtHeadGradSink hg{head ? reinterpret_cast<float *>(ws + p.off_pw1) : nullptr, p.pw1_stride};
+#define BWD_OCT(PAIR, FUSED, GRP)                                                                                   \
+    do {                                                                                                            \
+        if (int rc = set_lds(ft_bwd_oct<PAIR, FUSED, GRP, false>, lds)) return rc;                                  \
+        BT_LAUNCH(BTK_FT_BWD_LDS, s, (ft_bwd_oct<PAIR, FUSED, GRP, false>), grid, block, lds, grad_out, fs, out, saved, \
+                  stream, meta, pw, pb, *d, p.ntiles, cpi, p.chunks_per_wg, gp, p.rows_cap, hg);                    \
+    } while (0)
+#define BWD_OCT2(PAIR, FUSED)                  \
+    do {                                       \
+        if (p.grouped) BWD_OCT(PAIR, FUSED, true); \
+        else BWD_OCT(PAIR, FUSED, false);      \
+    } while (0)
+        if (head) {
+            if (int rc = set_lds(ft_bwd_oct<false, true, false, true>, lds)) return rc;
+            BT_LAUNCH(BTK_FT_BWD_LDS, s, (ft_bwd_oct<false, true, false, true>), grid, block, lds, grad_out, fs, out, saved,
+                      stream, meta, pw, pb, *d, p.ntiles, cpi, p.chunks_per_wg, gp, p.rows_cap, hg);
+        } else if (d->pairwise) {
+            if (fused) BWD_OCT2(true, true);
+            else BWD_OCT2(true, false);
+        } else {
+            if (fused) BWD_OCT2(false, true);
+            else BWD_OCT2(false, false);
+        }
+#undef BWD_OCT2
+#undef BWD_OCT
+    }
 #define BWD_LDS(KERNEL)                                                                                             \
     do {                                                                                                            \
         if (int rc = set_lds(KERNEL, lds)) return rc;                                                               \
@@ -1407,7 +2175,8 @@ int ft_backward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, 
         BT_LAUNCH(BTK_FT_BWD_LDS, s, (KERNEL), grid, block, lds, grad_out, fs, out, saved, sorted, offs, pw, pb, *d,  \
                   p.ntiles, cpi, p.chunks_per_wg, gp);                                                              \
     } while (0)
-    if (lean) {
+    if (p.oct) {
+    } else if (lean) {
         if (fused) BWD_LDS(ft_bwd_lds<true>);
         else BWD_LDS(ft_bwd_lds<false>);
     } else if (p.grouped) {
@@ -1430,7 +2199,14 @@ int ft_backward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, 
     BT_LAUNCH_CHECK();
     if (d->rows != d->stride) BT_HIP(hipMemsetAsync(dw, 0, (size_t)d->stride * d->cols * sizeof(float), s));
     const long long n = (long long)d->cols * (d->rows / 4) + d->rows;
-    if (p.grouped)
+    if (head) {
+        const int n1 = d->n_inputs * d->rows * fs.w1_rows, blocks_w = bt_div_up(n, 256);
+        const FtHeadMerge hm{reinterpret_cast<const float *>(ws + p.off_pw1), p.pw1_stride, head->dw1, head->db1,
+                             head->gz_parts, head->loss_partials, head->n_loss_partials, head->loss_sum, fs.w1_rows,
+                             p.chunks_per_input / p.chunks_per_wg, n1};
+        BT_LAUNCH(BTK_FT_BWD_MERGE, s, ft_bwd_merge_head, dim3(blocks_w + bt_div_up(n1, 256) + 1), dim3(256), 0, pw, pb, dw,
+                  dbias, *d, p.G, hm, blocks_w);
+    } else if (p.grouped)
         BT_LAUNCH(BTK_FT_BWD_MERGE, s, ft_bwd_merge_grp, dim3(bt_div_up(n, 256)), dim3(256), 0, pw, pb, dw, dbias, *d, p.tc,
                   reinterpret_cast<const int *>(ws + p.off_segitems), reinterpret_cast<const int *>(ws + p.off_counts));
     else
@@ -1446,22 +2222,32 @@ bool bt_internal_ft_fused_ok(const bt_ft_desc *d, int head_rows) {
     FtPlan p;
     if (ft_validate(d, "ft_fused_ok") || ft_plan(d, &p)) return false;
     return p.lds_path && !force_generic() && head_rows >= 1 && head_rows <= FtPlan::kFusedMaxRows &&
-           p.lds_bwd_bytes + (size_t)d->n_inputs * head_rows * 32 * sizeof(float) <= 160 * 1024;
+           (p.oct ? p.lds_oct_bytes : p.lds_bwd_bytes) + (size_t)d->n_inputs * head_rows * 32 * sizeof(float) <= 160 * 1024;
+}
+
+bool bt_internal_ft_fused_head_grad_ok(const bt_ft_desc *d, int head_rows) {
+    FtPlan p;
+    return bt_internal_ft_fused_ok(d, head_rows) && !ft_plan(d, &p) && p.hdw;
 }
 
 int bt_internal_ft_backward_fused(void *stream, const bt_ft_desc *d, const float *gz, const float *w1,
                                   const int32_t *bucket, int head_rows, const float *out, const float *saved, float *dw,
-                                  float *dbias, void *workspace, size_t workspace_bytes) {
+                                  float *dbias, void *workspace, size_t workspace_bytes, const bt_ft_head_grads *head) {
     if (int rc = ft_validate(d, "bt_ft_backward")) return rc;
     BT_REQUIRE(gz && w1 && dw && workspace, "bt_ft_backward(fused): null pointer");
     BT_REQUIRE(bt_internal_ft_fused_ok(d, head_rows), "bt_ft_backward(fused): shape not supported");
     FtPlan p;
     if (int rc = ft_plan(d, &p)) return rc;
     BT_REQUIRE(workspace_bytes >= p.total, "bt_ft_backward: workspace too small (%zu < %zu)", workspace_bytes, p.total);
+    if (head) {
+        BT_REQUIRE(p.hdw, "bt_ft_backward(fused): head gradients not supported for this shape");
+        BT_REQUIRE(head->dw1 && head->db1 && head->gz_parts && head->loss_partials && head->loss_sum && out,
+                   "bt_ft_backward(fused): null head gradient pointer");
+    }
     char *ws = static_cast<char *>(workspace);
     return ft_backward_lds_launch(bt_stream(stream), d, p, nullptr, FtFusedSrc{gz, w1, bucket, head_rows}, out, saved,
                                   reinterpret_cast<const uint16_t *>(ws + p.off_sorted),
-                                  reinterpret_cast<const uint32_t *>(ws + p.off_offs), ws, dw, dbias);
+                                  reinterpret_cast<const uint32_t *>(ws + p.off_offs), ws, dw, dbias, head);
 }
 
 namespace {
@@ -1615,6 +2401,22 @@ int bt_internal_ft_build_sorted(void *stream, const bt_ft_desc *d, const int32_t
     const int threads = p.index_waves * 64;
     const size_t lds = ((size_t)p.index_waves * p.tc + threads) * sizeof(uint32_t);
     const FtGrp gp = ft_grp(p, ws, false);
+    if (p.oct && !force_generic()) {
+        uint2 *stream = reinterpret_cast<uint2 *>(ws + p.off_stream);
+        uint8_t *meta = reinterpret_cast<uint8_t *>(ws + p.off_meta);
+        const size_t olds = oct_index_lds_bytes(p.tc);
+        if (p.grouped) {
+            if (int rc = set_lds(ft_index_oct_kernel<true>, olds)) return rc;
+            BT_LAUNCH(BTK_FT_INDEX, s, ft_index_oct_kernel<true>, dim3(p.nchunks), dim3(OCT_IDX_THREADS), olds, i0, i1,
+                      d->batch, d->nnz, p.tc, 1, p.fbits, stream, meta, gp, d->cols);
+        } else {
+            if (int rc = set_lds(ft_index_oct_kernel<false>, olds)) return rc;
+            BT_LAUNCH(BTK_FT_INDEX, s, ft_index_oct_kernel<false>, dim3(p.nchunks), dim3(OCT_IDX_THREADS), olds, i0, i1,
+                      d->batch, d->nnz, d->cols, p.chunks_per_input, p.fbits, stream, meta, gp, d->cols);
+        }
+        BT_LAUNCH_CHECK();
+        return BT_OK;
+    }
     if (p.grouped)
         BT_LAUNCH(BTK_FT_INDEX, s, ft_index_kernel<true>, dim3(p.nchunks), dim3(threads), lds, i0, i1, d->batch, d->nnz,
                   p.tc, 1, p.fbits, sorted, offs, gp, d->cols);
@@ -1625,6 +2427,14 @@ int bt_internal_ft_build_sorted(void *stream, const bt_ft_desc *d, const int32_t
     return BT_OK;
 }
 
+#ifdef BT_OCT_TIMING
+extern "C" int bt_oct_debug_read(unsigned long long *out) {
+    BT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(bt_oct_dbg), sizeof(unsigned long long) * 128));
+    unsigned long long z[128] = {0};
+    BT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(bt_oct_dbg), z, sizeof(z)));
+    return 0;
+}
+#endif
 // tests change the switches between cases of one process: they call this after touching the environment
 extern "C" void bt_internal_reload_env(void) { g_ft_env.reload(); }
 

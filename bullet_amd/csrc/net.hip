@@ -31,6 +31,7 @@ struct bt_net {
     float *loss_partials = nullptr;  // per-workgroup loss partials of the fused head forward
     int n_loss_partials = 0;
     float *zpart = nullptr;          // [n_inputs * row tiles][B] partial head outputs of the fused FT forward
+    float *gz_parts = nullptr;       // [loss partials][buckets] sums of gz0 by bucket (head bias gradient partials)
     bool fuse_loss = false, fuse_ft = false;
     float *a[BT_MAX_DENSE] = {nullptr}, *ga[BT_MAX_DENSE] = {nullptr};
     // layers with a dual activation / skip neurons: a[k] holds the raw outputs z, ap[k] what the next layer sees,
@@ -253,7 +254,7 @@ int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bo
         const int rc = bt_internal_head_finish(s, &q, n->zpart, bt_internal_ft_head_parts(&f), n->params + n->t_off[3], bk,
                                                b->targets, n->d.use_entry_weights ? b->entry_weights : nullptr, n->a[0],
                                                n->grad_y, want_gz0 ? n->gz0 : nullptr, n->loss_partials,
-                                               &n->n_loss_partials);
+                                               &n->n_loss_partials, want_gz0 ? n->gz_parts : nullptr);
         if (rc) (void)bt_take_stop_event(BTK_DENSE_FWD_SMALL);  // not launched: do not leave the event armed
         return rc;
     }
@@ -401,6 +402,7 @@ int bt_net_create(const bt_net_desc *desc, int max_batch, float *ext_params, flo
     if ((rc = dmalloc(&n->grad_y, B * desc->dense_out[desc->n_dense - 1]))) return fail(rc);
     if ((rc = dmalloc(&n->gz0, B))) return fail(rc);
     if ((rc = dmalloc(&n->loss_partials, 1024))) return fail(rc);
+    if ((rc = dmalloc(&n->gz_parts, (size_t)1024 * std::max(1, desc->num_buckets)))) return fail(rc);
     {
         bt_ft_desc fmax = ft_desc(n, B);
         if ((rc = dmalloc(&n->zpart, (size_t)(bt_internal_ft_head_parts(&fmax) + 1) * B))) return fail(rc);
@@ -453,7 +455,7 @@ int bt_net_destroy(bt_net *n) {
     if (n->own_params) bt_free(n->params);
     if (n->own_grads) bt_free(n->grads);
     bt_free(n->mom), bt_free(n->vel), bt_free(n->hid), bt_free(n->g_hid), bt_free(n->saved), bt_free(n->grad_y);
-    bt_free(n->gz0), bt_free(n->loss_partials), bt_free(n->zpart);
+    bt_free(n->gz0), bt_free(n->loss_partials), bt_free(n->zpart), bt_free(n->gz_parts);
     for (int k = 0; k < BT_MAX_DENSE; k++) bt_free(n->a[k]), bt_free(n->ga[k]), bt_free(n->ap[k]), bt_free(n->gzp[k]);
     bt_free(n->yfin), bt_free(n->weff), bt_free(n->slow), bt_free(n->perm);
     bt_free(n->ft_ws), bt_free(n->dense_ws);
@@ -572,6 +574,20 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
         BT_LAUNCH_CHECK();
         return BT_OK;
     };
+    if (side_head && head_in_ft && bt_internal_ft_fused_head_grad_ok(&f, q0.buckets)) {
+        // The FT backward forms the head's weight gradient from the activation tile it stages anyway (matrix cores,
+        // beside its LDS-bound reduction), and its merge kernel adds up the head's bias gradient and the loss from
+        // the finishing kernel's partials: no second stream, no second pass over the [B][2H] activations.
+        n->has_next = false;
+        const bt_ft_head_grads hg{n->grads + n->t_off[2], n->grads + n->t_off[3], n->gz_parts, n->loss_partials,
+                                  n->n_loss_partials, loss_sum_dev};
+        if (int rc = bt_internal_ft_backward_fused(s, &f, n->gz0, n->params + n->t_off[2],
+                                                   n->d.dense_bucketed[0] ? b->buckets : nullptr, q0.buckets, n->hid,
+                                                   n->saved, n->grads + n->t_off[0], n->grads + n->t_off[1], n->ft_ws,
+                                                   n->ft_ws_bytes, &hg))
+            return rc;
+        return factor_reduce();
+    }
     if (side_head) {
         // (a next-batch hint is not used here: this path's index build already hides under the forward pass, and
         // building the next one beside the FT backward instead was measured slower, 0.30 vs 0.27 ms)

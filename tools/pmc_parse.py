@@ -3,6 +3,7 @@
 import collections
 import csv
 import glob
+import re
 import sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
@@ -13,7 +14,7 @@ for f in sorted(glob.glob(f"{root}/**/*counter_collection.csv", recursive=True))
         k = r["Kernel_Name"]
         if "ft_" not in k:
             continue
-        k = k.split("::")[-1].split("(")[0]
+        k = re.search(r"(ft_\w+)", k).group(1)
         acc[(k, r["Counter_Name"])] += float(r["Counter_Value"])
         n[(k, r["Counter_Name"])] += 1
     for (k, c), v in acc.items():
