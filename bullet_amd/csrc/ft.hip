@@ -1524,6 +1524,11 @@ __device__ unsigned long long bt_oct_dbg[16 * 8];
 // (rows = buckets), the two entries sharing a k take turns through a zeroed half, and the 16 x 16 f32 accumulators
 // (one per float4 component) run through all chunks of the workgroup: an exact-f32 fma chain in a fixed order.
 typedef float oct_f32x4 __attribute__((ext_vector_type(4)));
+// Workgroup barrier for data that travels through LDS only: waits for this wave's LDS operations, not for its global
+// loads. __syncthreads() carries a workgroup-scope fence that drains vmcnt too, which makes a barrier of the chunk
+// loop wait for the loads fetched ahead for the NEXT chunk (stream rows, staging data) -- the latency those
+// prefetches exist to hide. Nothing in this kernel hands global data from one wave to another.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 struct FtHeadGradSink {
     float *pw1;         // [G][n_inputs * out_w * w1_rows] per-chunk-group partials of dW1 (column-major like w1)
     size_t pw1_stride;  // floats per chunk group
@@ -1672,7 +1677,7 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
         const int kc = GRP ? 0 : c / chunks_per_input;
         const int n_e = r_ne;
         OT(1);
-        __syncthreads();  // the previous chunk's readers are done with gt; its parts are complete
+        lds_barrier();  // the previous chunk's readers are done with gt; its parts are complete
         OT(2);
         // this wave's stream of the chunk: rows [r0, r0 + n), n a multiple of 4; the first two 4-row sets now
         const int r0 = __builtin_amdgcn_readfirstlane((int)p_r0), n = __builtin_amdgcn_readfirstlane((int)p_r1) - r0;
@@ -1729,7 +1734,7 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
             }
         }
         OT(3);
-        __syncthreads();
+        lds_barrier();
         OT(4);
         prefetch(min(c + 1, c_hi - 1));  // (the last chunk fetches itself again: unconditional on purpose, see above)
         OT(5);

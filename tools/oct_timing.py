@@ -1,19 +1,24 @@
 #!/usr/bin/env python3
-"""Developer experiment: per-phase cycle counts of ft_bwd_oct (workgroup 0, one row per wave), from a library built
-with -DBT_OCT_TIMING (BT_LIB_PATH=tools/libbullet_amd_timing.so python tools/oct_timing.py [occupancy])."""
+"""Developer experiment: per-phase cycle counts of ft_bwd_oct (workgroup 0, one row per wave) over the bench's
+training step, from a library built with -DBT_OCT_TIMING:
+BT_LIB_PATH=tools/libbullet_amd_timing.so python tools/oct_timing.py [bench args]"""
 import ctypes as C
 import os
-import runpy
 import sys
 
-sys.argv = [sys.argv[0], "3"] + sys.argv[1:]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-runpy.run_path(os.path.join(ROOT, "tools", "ft_microbench.py"), run_name="__main__")
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402,F401  (before the library: both must end up on torch's HIP runtime)
+import bench  # noqa: E402
 from bullet_amd import lib  # noqa: E402
+
+STEPS, WARM = 20, 2
+sys.argv = [sys.argv[0], "--steps", str(STEPS), "--warmup", str(WARM), "--no-cpu-baseline", "--no-profile"] + sys.argv[1:]
 L = lib.load()
 buf = (C.c_ulonglong * 128)()
+bench.main()
 assert L.bt_oct_debug_read(buf) == 0
-names = ["pre", "loop_tail", "waitA", "stage", "waitB", "prefetch", "reduce", "end"]
-print("wave " + " ".join(f"{n:>9s}" for n in names))
+names = ["prologue", "work", "loads", "waitX", "fixup", "waitY", "end", "-"]
+print("cycles per launch; wave " + " ".join(f"{n:>9s}" for n in names))
 for w in range(16):
-    print(f"{w:4d} " + " ".join(f"{buf[w * 8 + i] / 3:9.0f}" for i in range(8)))
+    print(f"{w:4d} " + " ".join(f"{buf[w * 8 + i] / (STEPS + WARM):9.0f}" for i in range(8)))
