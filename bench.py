@@ -327,47 +327,43 @@ def main():
 
 
 def cpu_baseline(batch, B):
-    """The CPU oracle (oracle/, a scalar port of the reference's CPU semantics: the reference has no CPU
-    backend of its own) on a bounded sample of the same workload: full training steps,
-    batch-parallel over the host cores (each thread runs the scalar oracle on a contiguous shard of the batch,
-    the shard gradients are summed, then AdamW), plus a few single-thread steps for the per-core figure."""
-    from concurrent.futures import ThreadPoolExecutor
+    """The CPU oracle (oracle/, a scalar C restatement of the reference's CPU semantics: the reference has no CPU
+    backend of its own) on a bounded sample of the same workload: full training steps, batch-parallel
+    over the host cores with the worker threads INSIDE the C library (orc_train_steps_mt: each thread runs forward +
+    backward on a contiguous shard, the shard gradients are added in order, then AdamW). Timed on the optimised build
+    (oracle/liboracle_fast.so, -O3 -march=x86-64-v3); the parity build (-O2 -ffp-contract=off,
+    the one the tests check against) is timed beside it and reported in `sample`."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
-    from bullet_amd import parallel
     do = ob.make_net(**CFG2)
-    params = ob.net_init(do)
-    m = [np.zeros_like(p) for p in params]
-    v = [np.zeros_like(p) for p in params]
     sample = min(B, 16384)
     stm, ntm, bk, tg, w = (np.ascontiguousarray(a[:sample]) for a in batch)
     cores = max(1, min(16, os.cpu_count() or 1))  # the GPU box gives one job 16 cores (MAX_JOBS there)
 
-    def shard_step(k, n):
-        lo, hi = parallel.shard_range(sample, k, n)
-        return ob.net_fwd_bwd(do, params, stm[lo:hi], ntm[lo:hi], bk[lo:hi], tg[lo:hi], w[lo:hi])[1]
+    def run(so, threads, budget_s, max_steps):
+        L = C.CDLL(os.path.join(ROOT, "oracle", so))
+        L.orc_train_steps_mt.restype = C.c_float
+        params = ob.net_init(do)
+        m, v = [np.zeros_like(p) for p in params], [np.zeros_like(p) for p in params]
+        args = (C.byref(do), sample, ob.ptr_array(params), ob.ptr_array(m), ob.ptr_array(v), ob.ip(stm), ob.ip(ntm),
+                ob.ip(bk), ob.fp(tg), ob.fp(w), threads)
+        t0 = time.perf_counter()
+        L.orc_train_steps_mt(*args, 1, C.c_float(1e-3))  # one step sizes the rest of the budget
+        per = time.perf_counter() - t0
+        more = int(max(0, min(max_steps - 1, (budget_s - per) / per)))
+        if more:
+            L.orc_train_steps_mt(*args, more, C.c_float(1e-3))
+        return 1 + more, time.perf_counter() - t0
 
-    def run(n, budget_s, max_steps, pool):
-        t0, steps = time.perf_counter(), 0
-        while True:
-            parts = list(pool.map(lambda k: shard_step(k, n), range(n))) if n > 1 else [shard_step(0, 1)]
-            for t, (p_, m_, v_) in enumerate(zip(params, m, v)):
-                g = parts[0][t]
-                for other in parts[1:]:
-                    g += other[t]
-                ob.adamw(p_, m_, v_, g, 1.0 / sample, 1e-3)
-            steps += 1
-            el = time.perf_counter() - t0
-            if el > budget_s or steps >= max_steps:
-                return steps, el
-
-    with ThreadPoolExecutor(cores) as pool:
-        s1, e1 = run(1, 3.0, 8, pool)
-        sn, en = run(cores, 10.0, 256, pool) if cores > 1 else (s1, e1)
+    s1, e1 = run("liboracle_fast.so", 1, 3.0, 8)
+    sn, en = run("liboracle_fast.so", cores, 10.0, 256)
+    sp, ep = run("liboracle.so", cores, 4.0, 64)
     return {"value": sample * sn / en, "unit": "positions/sec", "cores": cores, "kind": "port",
-            "single_core_value": sample * s1 / e1,
-            "sample": f"{sn} full training steps (fwd+bwd+AdamW) of {sample} positions on {cores} threads in {en:.1f} s "
-                      f"(+ {s1} single-thread steps in {e1:.1f} s), oracle/bullet_oracle.c -O2 scalar per thread"}
+            "single_core_value": sample * s1 / e1, "parity_build_value": sample * sp / ep,
+            "sample": f"{sn} full training steps (fwd+bwd+AdamW) of {sample} positions on {cores} threads inside "
+                      f"oracle/liboracle_fast.so (gcc -O3 -march=x86-64-v3, pthreads) in {en:.1f} s; + {s1} single-thread "
+                      f"steps in {e1:.1f} s; + {sp} steps of the parity build (-O2 -ffp-contract=off) on {cores} threads "
+                      f"in {ep:.1f} s"}
 
 
 if __name__ == "__main__":

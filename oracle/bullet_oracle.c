@@ -921,3 +921,75 @@ void orc_reduce_i32(const int32_t *in, size_t outer, size_t dimen, size_t inner,
             out[i * inner + j] = acc;
         }
 }
+
+/* ---- batch-parallel training steps for the CPU baseline of bench.py (the restatement run over all host
+ * cores with std::thread-style workers inside C; not used by any parity test). Each worker runs the scalar
+ * forward + backward on a contiguous shard of the batch into its own gradient buffers; the shard gradients are added
+ * in shard order and AdamW (adam.rs:43-51) steps every tensor. Returns the loss sum of the last step. */
+#include <pthread.h>
+
+typedef struct {
+    const orc_net_desc *d;
+    int lo, hi, nnz;
+    const float *const *params;
+    float **grads;
+    const int32_t *stm, *nstm, *buckets;
+    const float *targets, *weights;
+    float loss;
+} orc_mt_job;
+
+static void *orc_mt_worker(void *arg) {
+    orc_mt_job *j = (orc_mt_job *)arg;
+    const int n = j->hi - j->lo;
+    const int tw = j->d->loss_kind == ORC_LOSS_SOFTMAX_CE ? j->d->dense_out[j->d->n_dense - 1] : 1;
+    j->loss = n > 0 ? orc_net_forward_backward(j->d, n, j->params, j->grads, j->stm + (size_t)j->lo * j->nnz,
+                                               j->nstm ? j->nstm + (size_t)j->lo * j->nnz : NULL,
+                                               j->buckets ? j->buckets + j->lo : NULL, j->targets + (size_t)j->lo * tw,
+                                               j->weights ? j->weights + j->lo : NULL, NULL)
+                    : 0.0f;
+    return NULL;
+}
+
+float orc_train_steps_mt(const orc_net_desc *d, int batch, float *const *params, float *const *mom, float *const *vel,
+                         const int32_t *stm, const int32_t *nstm, const int32_t *buckets, const float *targets,
+                         const float *weights, int threads, int steps, float lr) {
+    const int nt = orc_net_num_tensors(d);
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    orc_mt_job *jobs = (orc_mt_job *)calloc((size_t)threads, sizeof(orc_mt_job));
+    pthread_t *tid = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    for (int t = 0; t < threads; t++) {
+        jobs[t].grads = (float **)calloc((size_t)nt, sizeof(float *));
+        for (int i = 0; i < nt; i++) jobs[t].grads[i] = (float *)calloc(orc_net_tensor_size(d, i), sizeof(float));
+    }
+    float loss = 0.0f;
+    for (int s = 0; s < steps; s++) {
+        for (int t = 0; t < threads; t++) {
+            orc_mt_job *j = &jobs[t];
+            j->d = d, j->nnz = d->nnz, j->params = (const float *const *)params;
+            j->lo = (int)((long long)batch * t / threads), j->hi = (int)((long long)batch * (t + 1) / threads);
+            j->stm = stm, j->nstm = nstm, j->buckets = buckets, j->targets = targets, j->weights = weights;
+            for (int i = 0; i < nt; i++) memset(j->grads[i], 0, orc_net_tensor_size(d, i) * sizeof(float));
+            if (threads > 1) pthread_create(&tid[t], NULL, orc_mt_worker, j);
+            else orc_mt_worker(j);
+        }
+        loss = 0.0f;
+        for (int t = 0; t < threads; t++) {
+            if (threads > 1) pthread_join(tid[t], NULL);
+            loss += jobs[t].loss;
+        }
+        for (int i = 0; i < nt; i++) {
+            const size_t n = orc_net_tensor_size(d, i);
+            float *g = jobs[0].grads[i];
+            for (int t = 1; t < threads; t++)
+                for (size_t q = 0; q < n; q++) g[q] += jobs[t].grads[i][q];
+            orc_adamw(params[i], mom[i], vel[i], g, n, 1.0f / (float)batch, lr, 0.01f, 0.9f, 0.999f, -1.98f, 1.98f);
+        }
+    }
+    for (int t = 0; t < threads; t++) {
+        for (int i = 0; i < nt; i++) free(jobs[t].grads[i]);
+        free(jobs[t].grads);
+    }
+    free(jobs), free(tid);
+    return loss;
+}

@@ -244,4 +244,10 @@ void orc_reduce_i32(const int32_t *in, size_t outer, size_t dimen, size_t inner,
 #ifdef __cplusplus
 }
 #endif
+/* bench.py's CPU baseline only: `steps` full training steps (forward + backward on `threads` contiguous shards of the
+ * batch in parallel, shard gradients added in order, AdamW with the reference defaults); returns the last loss sum */
+float orc_train_steps_mt(const orc_net_desc *d, int batch, float *const *params, float *const *mom, float *const *vel,
+                         const int32_t *stm, const int32_t *nstm, const int32_t *buckets, const float *targets,
+                         const float *weights, int threads, int steps, float lr);
+
 #endif
