@@ -21,6 +21,17 @@ int bt_internal_viri_source(const char *const *paths, int n_paths, size_t buffer
 
 void bt_set_error(const char *fmt, ...);
 
+// comm.cpp: a communicator is either RCCL (rccl = the ncclComm_t, with a stream of its own for the collectives and
+// events to fence it against the caller's stream) or the caller's hooks (collectives then go on the caller's stream)
+struct bt_comm {
+    int rank = 0, world = 1;
+    void *rccl = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool hooked = false;
+    bt_comm_hooks hooks = {};
+};
+
 #define BT_HIP(call)                                                              \
     do {                                                                          \
         hipError_t e_ = (call);                                                   \

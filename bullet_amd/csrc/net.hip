@@ -722,17 +722,91 @@ int bt_net_load_checkpoint(bt_net *n, void *stream, const char *dir) {
     return BT_OK;
 }
 
+// the element-wise update of `nt` tensors (AdamW, or RAdam at the current step count)
+static int opt_apply(bt_net *n, void *stream, int nt, const bt_adamw_tensor *tab, const float *adj_dev, const float *lr_dev) {
+    if (n->opt_kind == BT_OPT_ADAMW) return bt_adamw(stream, nt, tab, adj_dev, lr_dev);
+    return bt_radam(stream, nt, tab, adj_dev, lr_dev, n->opt_step, n->opt_thr);
+}
+static int opt_lookahead(bt_net *n, void *stream) {
+    if (n->opt_kind != BT_OPT_RANGER || n->opt_step % n->opt_k != 0) return BT_OK;
+    float *pp[1] = {n->params}, *ss[1] = {n->slow};
+    const size_t cnt[1] = {n->n_params};  // the flat buffers: padding floats are zero on both sides
+    return bt_lookahead(stream, 1, pp, ss, cnt, n->opt_alpha);
+}
+
 int bt_net_optimiser_step(bt_net *n, void *stream, const float *adj_dev, const float *lr_dev) {
     BT_REQUIRE(n, "bt_net_optimiser_step: null net");
-    if (n->opt_kind == BT_OPT_ADAMW) return bt_adamw(stream, n->n_tensors, n->adam, adj_dev, lr_dev);
-    n->opt_step++;  // RAdam::update / RangerLookahead::update count their calls (radam.rs:277, ranger.rs:88)
-    if (int rc = bt_radam(stream, n->n_tensors, n->adam, adj_dev, lr_dev, n->opt_step, n->opt_thr)) return rc;
-    if (n->opt_kind == BT_OPT_RANGER && n->opt_step % n->opt_k == 0) {
-        float *pp[1] = {n->params}, *ss[1] = {n->slow};
-        const size_t cnt[1] = {n->n_params};  // the flat buffers: padding floats are zero on both sides
-        return bt_lookahead(stream, 1, pp, ss, cnt, n->opt_alpha);
+    if (n->opt_kind != BT_OPT_ADAMW) n->opt_step++;  // RAdam::update / RangerLookahead::update count their calls (radam.rs:277, ranger.rs:88)
+    if (int rc = opt_apply(n, stream, n->n_tensors, n->adam, adj_dev, lr_dev)) return rc;
+    return opt_lookahead(n, stream);
+}
+
+// ---- data-parallel step (section 7 of the header; no counterpart in the reference)
+int bt_net_dp_plan(const bt_net_desc *desc, int world, int rank, size_t shard_min_floats, bt_dp_plan *plan) {
+    BT_REQUIRE(desc && plan && world >= 1 && rank >= 0 && rank < world, "bt_net_dp_plan: bad arguments");
+    const size_t flat = bt_net_param_count(desc);
+    BT_REQUIRE(flat > 0, "bt_net_dp_plan: invalid net description");
+    const size_t table = bt_net_tensor_size(desc, 0), min_floats = shard_min_floats ? shard_min_floats : BT_DP_SHARD_MIN_FLOATS;
+    *plan = bt_dp_plan{};
+    plan->tail_off = 0, plan->tail_n = flat + 1;
+    if (bt_net_num_tensors(desc) > 1 && table >= min_floats && table % (size_t)world == 0) {  // (world 1: the same path, a test aid)
+        plan->sharded = 1;
+        plan->table_n = table, plan->per_rank = table / (size_t)world, plan->slice_lo = plan->per_rank * (size_t)rank;
+        plan->tail_off = bt_net_tensor_offset(desc, 1);  // tensor 0 sits at offset 0 of the flat buffers
+        plan->tail_n = flat + 1 - plan->tail_off;
     }
     return BT_OK;
+}
+
+int bt_net_dp_step(bt_net *n, bt_comm *c, void *stream, const float *adj_dev, const float *lr_dev, size_t shard_min_floats) {
+    BT_REQUIRE(n && adj_dev && lr_dev, "bt_net_dp_step: null argument");
+    if (!c) return bt_net_optimiser_step(n, stream, adj_dev, lr_dev);
+    bt_dp_plan pl;
+    if (int rc = bt_net_dp_plan(&n->d, c->world, c->rank, shard_min_floats, &pl)) return rc;
+    if (pl.sharded && c->hooked && !c->hooks.reduce_scatter) {  // hooks without the pair: replicated step
+        pl.sharded = 0, pl.tail_off = 0, pl.tail_n = n->n_params + 1;
+    }
+    hipStream_t s = bt_stream(stream);
+    // collectives on the communicator's stream when it has one (RCCL), fenced by events; else in `stream` order
+    hipStream_t cs = c->stream ? c->stream : s;
+    const bool fenced = cs != s;
+    auto fence = [&](hipStream_t from, hipStream_t to, hipEvent_t ev) -> int {
+        if (!fenced) return BT_OK;
+        BT_HIP(hipEventRecord(ev, from));
+        BT_HIP(hipStreamWaitEvent(to, ev, 0));
+        return BT_OK;
+    };
+    if (!pl.sharded) {
+        if (int rc = bt_allreduce_sum_f32(c, stream, n->grads, pl.tail_n)) return rc;
+        return bt_net_optimiser_step(n, stream, adj_dev, lr_dev);
+    }
+    if (n->opt_kind != BT_OPT_ADAMW) n->opt_step++;
+    if (int rc = fence(s, cs, c->ev[0])) return rc;  // the backward is done
+    if (int rc = bt_allreduce_sum_f32(c, cs, n->grads + pl.tail_off, pl.tail_n)) return rc;
+    if (int rc = fence(cs, s, c->ev[1])) return rc;
+    // (in place: rank r's sum lands in its own slice of the gradient)
+    if (int rc = bt_reduce_scatter_sum_f32(c, cs, n->grads, n->grads + pl.slice_lo, pl.per_rank)) return rc;
+    // every tensor but the table, on every rank, while the table's gradient is still on the wire
+    if (int rc = opt_apply(n, stream, n->n_tensors - 1, n->adam + 1, adj_dev, lr_dev)) return rc;
+    if (int rc = fence(cs, s, c->ev[2])) return rc;
+    bt_adamw_tensor own = n->adam[0];  // this rank's slice of the table
+    own.grad += pl.slice_lo, own.param += pl.slice_lo, own.momentum += pl.slice_lo, own.velocity += pl.slice_lo;
+    own.n = pl.per_rank;
+    if (int rc = opt_apply(n, stream, 1, &own, adj_dev, lr_dev)) return rc;
+    if (int rc = fence(s, cs, c->ev[3])) return rc;
+    if (int rc = bt_allgather_f32(c, cs, n->params + pl.slice_lo, n->params, pl.per_rank)) return rc;
+    if (int rc = fence(cs, s, c->ev[0])) return rc;
+    return opt_lookahead(n, stream);
+}
+
+int bt_net_dp_gather_state(bt_net *n, bt_comm *c, void *stream, size_t shard_min_floats) {
+    BT_REQUIRE(n, "bt_net_dp_gather_state: null net");
+    if (!c) return BT_OK;
+    bt_dp_plan pl;
+    if (int rc = bt_net_dp_plan(&n->d, c->world, c->rank, shard_min_floats, &pl)) return rc;
+    if (!pl.sharded || (c->hooked && !c->hooks.all_gather)) return BT_OK;
+    if (int rc = bt_allgather_f32(c, stream, n->mom + pl.slice_lo, n->mom, pl.per_rank)) return rc;
+    return bt_allgather_f32(c, stream, n->vel + pl.slice_lo, n->vel, pl.per_rank);
 }
 
 int bt_net_set_optimiser(bt_net *n, int kind, float n_sma_threshold, float alpha, int k) {

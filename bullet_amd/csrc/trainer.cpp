@@ -441,14 +441,19 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
     const int BG = cfg->batch_size, nnz = bt_input_max_active(input);
     const int dp_world = cfg->dp_world > 1 ? cfg->dp_world : 1, dp_rank = dp_world > 1 ? cfg->dp_rank : 0;
     BT_REQUIRE(dp_rank >= 0 && dp_rank < dp_world, "bt_train_run: dp_rank out of range");
-    BT_REQUIRE(dp_world == 1 || cfg->grad_sync, "bt_train_run: data-parallel training needs grad_sync");
+    bt_comm *comm = static_cast<bt_comm *>(cfg->comm);
+    BT_REQUIRE(dp_world == 1 || cfg->grad_sync || comm, "bt_train_run: data-parallel training needs comm or grad_sync");
+    BT_REQUIRE(!comm || (bt_comm_world(comm) == dp_world && bt_comm_rank(comm) == dp_rank),
+               "bt_train_run: comm has rank %d of %d, the configuration says %d of %d", bt_comm_rank(comm),
+               bt_comm_world(comm), dp_rank, dp_world);
     const int shard_base = BG / dp_world, shard_rem = BG % dp_world;
     const int lo = dp_rank * shard_base + (dp_rank < shard_rem ? dp_rank : shard_rem);
     const int B = shard_base + (dp_rank < shard_rem ? 1 : 0);
     BT_REQUIRE(B > 0, "bt_train_run: batch_size smaller than dp_world");
     BT_REQUIRE(B <= bt_net_max_batch(net), "bt_train_run: Mismatched sizes! (net max_batch < batch shard)");
-    const bool dp = dp_world > 1;
+    const bool dp = dp_world > 1 || comm != nullptr;  // (a communicator of one rank still goes through the exchange)
     const bool loss_slot = dp && (cfg->dp_loss_slot || bt_net_grads_owned(net));
+    BT_REQUIRE(!(dp && comm) || loss_slot, "bt_train_run: comm needs the loss slot behind the gradient (dp_loss_slot)");
     const size_t tw = cfg->wdl_output ? 3 : 1;  // targets per position (value.rs:74)
     const int bps = cfg->batches_per_superbatch;
     BT_REQUIRE(cfg->stop_superbatch <= 0 ||
@@ -760,7 +765,9 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
         // 4-byte store over PCIe instead of a copy packet on the compute stream
         float *loss_at = loss_slot ? bt_net_grads(net) + bt_net_flat_size(net) : dp ? loss_dev + ring : loss_host + ring;
         TRY(bt_net_forward_backward(net, compute_stream, &bb, loss_at));
-        if (dp) {
+        if (dp && comm) {  // exchange + optimiser in one call: RCCL from C, the table sharded when it is large
+            TRY(bt_net_dp_step(net, comm, compute_stream, adj_dev, lr_dev + ring, cfg->dp_shard_min_floats));
+        } else if (dp) {
             auto sync = [&](float *buf, size_t n) -> int {
                 if (cfg->grad_sync(cfg->grad_sync_user, buf, n, compute_stream)) {
                     bt_set_error("bt_train_run: grad_sync failed");
@@ -771,7 +778,7 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
             TRY(sync(bt_net_grads(net), bt_net_flat_size(net) + (loss_slot ? 1 : 0)));
             if (!loss_slot) TRY(sync(loss_at, 1));
         }
-        TRY(bt_net_optimiser_step(net, compute_stream, adj_dev, lr_dev + ring));
+        if (!(dp && comm)) TRY(bt_net_optimiser_step(net, compute_stream, adj_dev, lr_dev + ring));
         TRY_HIP(hipEventRecord(consumed[set], bt_stream(compute_stream)));
         if (dp) TRY(bt_memcpy_d2h_async(loss_host + ring, loss_at, sizeof(float), compute_stream));
         TRY_HIP(hipEventRecord(loss_ready[ring], bt_stream(compute_stream)));
@@ -784,6 +791,7 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
         if (++batch == bps) batch = 0, sb++;
     }
     TRY(deliver(true));
+    if (dp && comm) TRY(bt_net_dp_gather_state(net, comm, compute_stream, cfg->dp_shard_min_floats));
     TRY(bt_stream_sync(compute_stream));
     if (cfg->log_rate > 0) {
         const unsigned total = (unsigned)secs(t_start, clock::now());

@@ -105,7 +105,22 @@ class TrainConfig(C.Structure):
                 ("dp_rank", C.c_int), ("dp_world", C.c_int), ("grad_sync", C.c_void_p),
                 ("grad_sync_user", C.c_void_p), ("dp_loss_slot", C.c_int), ("stop_superbatch", C.c_int), ("reader", C.c_void_p),
                 ("lr_fn", C.c_void_p), ("wdl_fn", C.c_void_p), ("sched_user", C.c_void_p),
-                ("blend_fn", C.c_void_p), ("weight_fn", C.c_void_p), ("fn_user", C.c_void_p)]
+                ("blend_fn", C.c_void_p), ("weight_fn", C.c_void_p), ("fn_user", C.c_void_p),
+                ("comm", C.c_void_p), ("dp_shard_min_floats", C.c_size_t)]
+
+
+COMM_ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+COMM_SCATTER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class CommHooks(C.Structure):
+    _fields_ = [("all_reduce", COMM_ALLREDUCE_CB), ("reduce_scatter", COMM_SCATTER_CB), ("all_gather", COMM_SCATTER_CB),
+                ("user", C.c_void_p)]
+
+
+class DpPlan(C.Structure):
+    _fields_ = [("sharded", C.c_int), ("table_n", C.c_size_t), ("per_rank", C.c_size_t), ("slice_lo", C.c_size_t),
+                ("tail_off", C.c_size_t), ("tail_n", C.c_size_t)]
 
 
 BATCH_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_float)
@@ -142,6 +157,9 @@ SYMBOLS = [
     "bt_train_run",
     "bt_net_tensor_name", "bt_net_tensor_shape", "bt_checkpoint_write", "bt_checkpoint_read", "bt_save_quantised",
     "bt_save_raw", "bt_net_save_checkpoint", "bt_net_load_checkpoint",
+    "bt_comm_unique_id", "bt_comm_init_rank", "bt_comm_from_hooks", "bt_comm_destroy", "bt_comm_rank", "bt_comm_world",
+    "bt_allreduce_sum_f32", "bt_reduce_scatter_sum_f32", "bt_allgather_f32",
+    "bt_net_dp_plan", "bt_net_dp_step", "bt_net_dp_gather_state",
 ]
 
 _lib = None
@@ -242,6 +260,17 @@ def load():
     L.bt_reader_close.argtypes = [C.c_void_p]
     L.bt_train_run.argtypes = [C.c_void_p, C.POINTER(InputDesc), C.POINTER(TrainConfig), C.POINTER(C.c_char_p), C.c_int,
                                BATCH_CB, SUPERBATCH_CB, C.c_void_p]
+    L.bt_comm_unique_id.argtypes = [C.c_void_p]
+    L.bt_comm_init_rank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.bt_comm_from_hooks.argtypes = [C.POINTER(CommHooks), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    for f in ("bt_comm_destroy", "bt_comm_rank", "bt_comm_world"):
+        getattr(L, f).argtypes = [C.c_void_p]
+    L.bt_allreduce_sum_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.bt_reduce_scatter_sum_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.bt_allgather_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.bt_net_dp_plan.argtypes = [C.POINTER(NetDesc), C.c_int, C.c_int, C.c_size_t, C.POINTER(DpPlan)]
+    L.bt_net_dp_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.bt_net_dp_gather_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     _lib = L
     return L
 
@@ -377,17 +406,24 @@ class Net:
 
     def train(self, input_desc, paths, batch_size, batches_per_superbatch, end_superbatch, lr, wdl, eval_scale=400.0,
               start_superbatch=1, out_buckets=1, threads=4, log_rate=0, win_rate_model=False, on_batch=None,
-              on_superbatch=None, wdl_output=False, device_mapper=False, dist=None, reader=None):
+              on_superbatch=None, wdl_output=False, device_mapper=False, dist=None, reader=None, comm=None,
+              shard_min_floats=0):
         """run::train through the C ABI. lr / wdl: LrSched / WdlSched. Returns [(superbatch, running_loss, pos/s)].
         dist: an initialised torch.distributed module -> data-parallel training (bt_train_config.dp_*): `batch_size`
         is the global batch, this rank trains on its shard, and the step buffer (flat gradient + loss sum) is
-        all-reduced once per step on the training loop's compute stream (RCCL when the backend is "nccl")."""
+        all-reduced once per step on the training loop's compute stream (RCCL when the backend is "nccl").
+        comm: a parallel.Comm (bt_comm: native RCCL, or hooks) instead of `dist` -- the loop then exchanges through
+        bt_net_dp_step (no Python on the step path; a table of >= shard_min_floats floats is sharded)."""
         import torch
         torch.cuda.synchronize()
         cfg = TrainConfig(batch_size, batches_per_superbatch, start_superbatch, end_superbatch, lr, wdl, eval_scale,
                           out_buckets, int(win_rate_model), threads, log_rate, int(wdl_output), int(device_mapper))
         sync_cb, sync_err = None, []
-        if dist is not None and dist.get_world_size() > 1:
+        if comm is not None:  # (a communicator of one rank still goes through bt_net_dp_step)
+            cfg.dp_rank, cfg.dp_world, cfg.dp_loss_slot = comm.rank, comm.world, 1
+            cfg.comm, cfg.dp_shard_min_floats = comm.h, shard_min_floats
+            sync_err = comm.errors
+        elif dist is not None and dist.get_world_size() > 1:
             def grad_sync(_u, buf, n, stream):
                 try:
                     if buf != self._gbuf.data_ptr() or n > self._gbuf.numel():

@@ -36,3 +36,110 @@ def allreduce_step_buffers(dist, step_buffer):
 def adj_factor(global_batch):
     """gradient_factor of run.rs:130 for the GLOBAL batch"""
     return 1.0 / float(global_batch)
+
+
+class _DeviceFloats:
+    """n floats at a raw device address, for torch.as_tensor (device memory plumbing only)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+def device_view(ptr, n):
+    import torch
+    return torch.as_tensor(_DeviceFloats(ptr, n), device="cuda")
+
+
+class Comm:
+    """Owner of a bt_comm (section 7 of include/bullet_amd.h). `Comm.rccl(dist)` is the product path: a native RCCL
+    communicator, one rank per process and GPU -- torch.distributed only carries the 128-byte id from rank 0 to the
+    others. `Comm.from_torch(dist)` wraps torch.distributed's own collectives as hooks (gloo staged through the host:
+    the two-ranks-on-one-GPU tests, where RCCL cannot run)."""
+
+    def __init__(self, handle, rank, world, keep=()):
+        self.h, self.rank, self.world, self._keep, self.errors = handle, rank, world, keep, []
+
+    @classmethod
+    def rccl(cls, dist=None):
+        import ctypes as C
+        from . import lib
+        L = lib.load()
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+        ident = C.create_string_buffer(128)
+        if rank == 0:
+            lib.check(L.bt_comm_unique_id(ident))
+        if world > 1:
+            box = [ident.raw]
+            dist.broadcast_object_list(box, src=0)
+            ident = C.create_string_buffer(box[0], 128)
+        h = C.c_void_p()
+        lib.check(L.bt_comm_init_rank(ident, rank, world, C.byref(h)))
+        return cls(h, rank, world)
+
+    @classmethod
+    def from_torch(cls, dist):
+        import ctypes as C
+        import torch
+        from . import lib
+        L = lib.load()
+        rank, world = dist.get_rank(), dist.get_world_size()
+        staged = dist.get_backend() == "gloo"
+        self = cls(None, rank, world)
+
+        def guarded(fn):
+            def call(*a):
+                try:
+                    with torch.cuda.stream(torch.cuda.ExternalStream(a[-1])):
+                        fn(*a[1:-1])
+                    return 0
+                except Exception as e:  # an exception must not unwind through the C frames
+                    self.errors.append(e)
+                    return 1
+            return call
+
+        def all_reduce(buf, n):
+            t = device_view(buf, n)
+            if staged:
+                host = t.cpu()
+                dist.all_reduce(host)
+                t.copy_(host)
+            else:
+                dist.all_reduce(t)
+
+        def reduce_scatter(send, recv, n):
+            s, r = device_view(send, n * world), device_view(recv, n)
+            if staged:
+                host = s.cpu()
+                dist.all_reduce(host)
+                r.copy_(host[rank * n:(rank + 1) * n])
+            else:
+                dist.reduce_scatter_tensor(r, s)
+
+        def all_gather(send, recv, n):
+            s, r = device_view(send, n), device_view(recv, n * world)
+            if staged:
+                parts = [torch.empty(n) for _ in range(world)]
+                dist.all_gather(parts, s.cpu())
+                r.copy_(torch.cat(parts))
+            else:
+                dist.all_gather_into_tensor(r, s)
+
+        hooks = lib.CommHooks(lib.COMM_ALLREDUCE_CB(guarded(all_reduce)), lib.COMM_SCATTER_CB(guarded(reduce_scatter)),
+                              lib.COMM_SCATTER_CB(guarded(all_gather)), None)
+        h = C.c_void_p()
+        lib.check(L.bt_comm_from_hooks(C.byref(hooks), rank, world, C.byref(h)))
+        self.h, self._keep = h, (hooks,)
+        return self
+
+    def all_reduce(self, tensor, stream=None):
+        """in-place sum of a float32 device tensor over the ranks (bt_allreduce_sum_f32)"""
+        import torch
+        from . import lib
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        lib.check(lib.load().bt_allreduce_sum_f32(self.h, s, tensor.data_ptr(), tensor.numel()))
+
+    def close(self):
+        if self.h:
+            from . import lib
+            lib.load().bt_comm_destroy(self.h)
+            self.h = None

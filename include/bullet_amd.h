@@ -515,6 +515,11 @@ typedef struct {
     float (*blend_fn)(void *user, const void *record32, float blend);
     float (*weight_fn)(void *user, const void *record32);
     void *fn_user;
+    /* non-NULL (a bt_comm of section 7, world = dp_world, rank = dp_rank): the loop exchanges gradients through it
+     * with bt_net_dp_step -- RCCL issued from C, nothing of the host language on the step path -- and `grad_sync` is
+     * not used. The net needs a library-owned gradient buffer or dp_loss_slot = 1. */
+    void *comm;
+    size_t dp_shard_min_floats; /* bt_net_dp_plan's threshold; 0 = BT_DP_SHARD_MIN_FLOATS */
 } bt_train_config;
 /* run::measure_max_cpu_throughput (run.rs:47-73): reader + host mapper alone over the schedule of `cfg` (no device
  * work); reports per superbatch when cfg->log_rate > 0 and returns the overall positions per second. */
@@ -574,6 +579,62 @@ int bt_save_raw(const bt_net_desc *desc, const float *flat_host, const bt_saved_
  * (optimiser.rs:232-236): weights, momentum and velocity back onto the device. */
 int bt_net_save_checkpoint(bt_net *net, void *stream, const bt_saved_format *fmt, int n_fmt, const char *dir);
 int bt_net_load_checkpoint(bt_net *net, void *stream, const char *dir);
+
+/* ------------------------------------------------------------------------------------------
+ * 7. Data-parallel exchange (no counterpart in the reference: it drives ONE device, run.rs:84, and holds no
+ *    collective library -- SURVEY.md 8e). One process per GPU; RCCL over xGMI, bound at run time (dlopen of
+ *    librccl), so the library still loads on a host without it.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct bt_comm bt_comm;
+/* Rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any means (a file, a socket,
+ * torch.distributed's store ...); every rank then joins with its own GPU current (bt_device_set). */
+#define BT_COMM_ID_BYTES 128
+int bt_comm_unique_id(void *id128);
+int bt_comm_init_rank(const void *id128, int rank, int world, bt_comm **comm);
+/* A communicator whose collectives are the caller's functions (another collective library; gloo staged through the
+ * host in the tests). Each sums / gathers floats in device memory, ordered after the work already enqueued on
+ * `stream` and before what is enqueued on it afterwards; returns 0 on success. reduce_scatter: rank r receives the
+ * sum of everyone's send[r*n .. (r+1)*n) (recv may be send + rank*n); all_gather: recv[r*n .. (r+1)*n) = rank r's
+ * send (send may be recv + rank*n). reduce_scatter / all_gather may be NULL: the table is then never sharded. */
+typedef struct {
+    int (*all_reduce)(void *user, float *buf_dev, size_t n, void *stream);
+    int (*reduce_scatter)(void *user, const float *send_dev, float *recv_dev, size_t n_per_rank, void *stream);
+    int (*all_gather)(void *user, const float *send_dev, float *recv_dev, size_t n_per_rank, void *stream);
+    void *user;
+} bt_comm_hooks;
+int bt_comm_from_hooks(const bt_comm_hooks *hooks, int rank, int world, bt_comm **comm);
+int bt_comm_destroy(bt_comm *comm);
+int bt_comm_rank(const bt_comm *comm);
+int bt_comm_world(const bt_comm *comm);
+/* In-place sum over ranks / reduce-scatter / all-gather of f32 in device memory, in `stream` order. */
+int bt_allreduce_sum_f32(bt_comm *comm, void *stream, float *buf_dev, size_t n);
+int bt_reduce_scatter_sum_f32(bt_comm *comm, void *stream, const float *send_dev, float *recv_dev, size_t n_per_rank);
+int bt_allgather_f32(bt_comm *comm, void *stream, const float *send_dev, float *recv_dev, size_t n_per_rank);
+
+/* How one step's exchange is split (host arithmetic only). A feature-transformer table (tensor 0, "l0w") of at
+ * least `shard_min_floats` floats whose size divides by `world` is SHARDED: its gradient is reduce-scattered, rank r
+ * runs the optimiser on floats [slice_lo, slice_lo + per_rank) of it only (and keeps momentum / velocity current for
+ * that slice only), and the updated slices are all-gathered; the other tensors (and the loss slot behind the flat
+ * gradient) are all-reduced as one message [tail_off, tail_off + tail_n) and stepped on every rank. Otherwise
+ * sharded = 0 and the whole flat gradient + loss slot is one all-reduce. Every optimiser here is element-wise, so the
+ * sharded step writes the same bits as the replicated one. shard_min_floats = 0 picks BT_DP_SHARD_MIN_FLOATS. */
+#define BT_DP_SHARD_MIN_FLOATS ((size_t)1 << 22)
+typedef struct {
+    int sharded;
+    size_t table_n, per_rank, slice_lo; /* sharded only */
+    size_t tail_off, tail_n;            /* the all-reduced range of the flat gradient, INCLUDING the loss slot */
+} bt_dp_plan;
+int bt_net_dp_plan(const bt_net_desc *desc, int world, int rank, size_t shard_min_floats, bt_dp_plan *plan);
+/* One data-parallel optimiser step after bt_net_forward_backward(net, stream, shard, loss): exchanges the gradient as
+ * bt_net_dp_plan says and applies bt_net_optimiser_step's update (adj = 1 / GLOBAL batch). The loss sum must sit in
+ * the slot behind the flat gradient (bt_net_grads(net) + bt_net_flat_size(net)) and is summed with it. With an RCCL
+ * communicator the collectives run on the communicator's own stream, fenced by events against `stream`, so the
+ * table's reduce-scatter overlaps the optimiser step of the other tensors. comm == NULL: a plain step. */
+int bt_net_dp_step(bt_net *net, bt_comm *comm, void *stream, const float *adj_dev, const float *lr_dev,
+                   size_t shard_min_floats);
+/* After sharded steps momentum / velocity are current on their owner only: all-gather them (before a checkpoint).
+ * bt_train_run does this before it returns. No-op when the plan is not sharded. */
+int bt_net_dp_gather_state(bt_net *net, bt_comm *comm, void *stream, size_t shard_min_floats);
 
 #ifdef __cplusplus
 }

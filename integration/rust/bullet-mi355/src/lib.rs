@@ -131,6 +131,32 @@ pub mod ffi {
         pub blend_fn: Option<unsafe extern "C" fn(user: *mut c_void, record32: *const c_void, blend: f32) -> f32>,
         pub weight_fn: Option<unsafe extern "C" fn(user: *mut c_void, record32: *const c_void) -> f32>,
         pub fn_user: *mut c_void,
+        pub comm: *mut c_void,
+        pub dp_shard_min_floats: usize,
+    }
+
+    #[repr(C)]
+    #[derive(Clone, Copy)]
+    pub struct bt_comm_hooks {
+        pub all_reduce: Option<unsafe extern "C" fn(user: *mut c_void, buf_dev: *mut f32, n: usize, stream: *mut c_void) -> c_int>,
+        pub reduce_scatter: Option<
+            unsafe extern "C" fn(user: *mut c_void, send_dev: *const f32, recv_dev: *mut f32, n_per_rank: usize, stream: *mut c_void) -> c_int,
+        >,
+        pub all_gather: Option<
+            unsafe extern "C" fn(user: *mut c_void, send_dev: *const f32, recv_dev: *mut f32, n_per_rank: usize, stream: *mut c_void) -> c_int,
+        >,
+        pub user: *mut c_void,
+    }
+
+    #[repr(C)]
+    #[derive(Clone, Copy, Debug, Default)]
+    pub struct bt_dp_plan {
+        pub sharded: c_int,
+        pub table_n: usize,
+        pub per_rank: usize,
+        pub slice_lo: usize,
+        pub tail_off: usize,
+        pub tail_n: usize,
     }
 
     #[repr(C)]
@@ -214,6 +240,18 @@ pub mod ffi {
             net: *mut bt_net, stream: *mut c_void, fmt: *const bt_saved_format, n_fmt: c_int, dir: *const c_char,
         ) -> c_int;
         pub fn bt_net_load_checkpoint(net: *mut bt_net, stream: *mut c_void, dir: *const c_char) -> c_int;
+
+        // section 7: data-parallel exchange (RCCL bound at run time; bt_comm is opaque, passed as *mut c_void)
+        pub fn bt_comm_unique_id(id128: *mut c_void) -> c_int;
+        pub fn bt_comm_init_rank(id128: *const c_void, rank: c_int, world: c_int, comm: *mut *mut c_void) -> c_int;
+        pub fn bt_comm_from_hooks(hooks: *const bt_comm_hooks, rank: c_int, world: c_int, comm: *mut *mut c_void) -> c_int;
+        pub fn bt_comm_destroy(comm: *mut c_void) -> c_int;
+        pub fn bt_allreduce_sum_f32(comm: *mut c_void, stream: *mut c_void, buf_dev: *mut f32, n: usize) -> c_int;
+        pub fn bt_net_dp_plan(desc: *const bt_net_desc, world: c_int, rank: c_int, shard_min_floats: usize, plan: *mut bt_dp_plan) -> c_int;
+        pub fn bt_net_dp_step(
+            net: *mut bt_net, comm: *mut c_void, stream: *mut c_void, adj_dev: *const f32, lr_dev: *const f32, shard_min_floats: usize,
+        ) -> c_int;
+        pub fn bt_net_dp_gather_state(net: *mut bt_net, comm: *mut c_void, stream: *mut c_void, shard_min_floats: usize) -> c_int;
 
         pub fn bt_input_init(d: *mut bt_input_desc, kind: c_int, factorised: c_int, layout: *const c_int, layout_len: c_int) -> c_int;
         pub fn bt_input_num_inputs(d: *const bt_input_desc) -> c_int;

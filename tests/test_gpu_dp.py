@@ -27,9 +27,13 @@ CFG_MULTI = dict(num_inputs=768 * 4, nnz=32, ft_out=128, ft_act="crelu", pairwis
 BATCH, BPS, SBS = 1001, 3, 2  # odd batch: uneven shards
 
 
-def _run(dist, device_mapper, kind="single"):
+def _run(dist, device_mapper, kind="single", mode="dist", comm=None):
+    """mode "dist": the grad_sync hook over torch.distributed; "comm" / "sharded": a bt_comm (bt_net_dp_step), the
+    second with the table forced onto the sharded path (reduce-scatter, optimiser on the own slice, all-gather)"""
     from bullet_amd import lib, parallel
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+    if dist is not None and mode != "dist":
+        comm, dist = parallel.Comm.from_torch(dist), None
     lo, hi = parallel.shard_range(BATCH, rank, world)
     multi = kind == "multi"
     net = lib.Net(lib.make_net_desc(**(CFG_MULTI if multi else CFG)), hi - lo)
@@ -39,13 +43,17 @@ def _run(dist, device_mapper, kind="single"):
     rep = net.train(idesc, [GOLDEN], BATCH, BPS, SBS,
                     lib.LrSched(lib.LR["constant"], 0.001, 0, 0, 0), lib.WdlSched(lib.WDL["constant"], 0.3, 0, 0),
                     out_buckets=8, threads=2, on_batch=lambda sb, b, l: losses.append(l),
-                    device_mapper=device_mapper, dist=dist)
+                    device_mapper=device_mapper, dist=dist, comm=comm, shard_min_floats=1024 if mode == "sharded" else 0)
     params = net.params.detach().cpu().numpy().copy()
+    if mode == "sharded":  # the optimiser state was gathered before bt_train_run returned: part of the comparison
+        n = net.n_flat
+        state = [parallel.device_view(f(net.h), n).cpu().numpy().copy() for f in (net.L.bt_net_momentum, net.L.bt_net_velocity)]
+        params = np.concatenate([params] + state)
     net.close()
     return losses, [r[1] for r in rep], params
 
 
-def _worker(rank, world, port, device_mapper, q, kind="single"):
+def _worker(rank, world, port, device_mapper, q, kind="single", mode="dist"):
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
     sys.path.insert(0, os.path.dirname(here))
@@ -55,15 +63,17 @@ def _worker(rank, world, port, device_mapper, q, kind="single"):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        q.put((rank,) + _run(dist, device_mapper, kind))
+        q.put((rank,) + _run(dist, device_mapper, kind, mode))
     except Exception as e:  # report instead of hanging the parent on q.get
         q.put((rank, repr(e), None, None))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("device_mapper,kind", [(False, "single"), (True, "single"), (True, "multi")])
-def test_two_rank_train_run_matches_single_process(device_mapper, kind):
+@pytest.mark.parametrize("device_mapper,kind,mode", [(False, "single", "dist"), (True, "single", "dist"),
+                                                     (True, "multi", "dist"), (True, "single", "comm"),
+                                                     (False, "single", "sharded"), (True, "multi", "sharded")])
+def test_two_rank_train_run_matches_single_process(device_mapper, kind, mode):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -72,7 +82,7 @@ def test_two_rank_train_run_matches_single_process(device_mapper, kind):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, device_mapper, q, kind)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, device_mapper, q, kind, mode)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -88,8 +98,39 @@ def test_two_rank_train_run_matches_single_process(device_mapper, kind):
         assert not isinstance(r[1], str), r[1]
     (_, l0, sb0, p0), (_, l1, sb1, p1) = res
     assert l0 == l1 and sb0 == sb1 and np.array_equal(p0, p1)  # replicas bit-identical
-    ref_l, ref_sb, ref_p = _run(None, device_mapper, kind)
+    ref_l, ref_sb, ref_p = _run(None, device_mapper, kind, mode)
     assert len(l0) == BPS * SBS == len(ref_l)
     for a, b in zip(l0, ref_l):
         assert abs(a - b) <= 1e-5 * abs(b)
     assert np.allclose(p0, ref_p, rtol=1e-4, atol=2e-6)
+
+
+def test_rccl_communicator_of_one_rank():
+    """The native RCCL binding (bt_comm_unique_id / bt_comm_init_rank / the three collectives) on the one GPU of the
+    test box: with a single rank every collective is the identity, and a training run through the communicator --
+    once replicated, once with the table forced onto the sharded path -- must write the bits of the plain run.
+    More ranks need one GPU each: the driver's 8-GPU bench is the first place RCCL moves data between devices."""
+    import ctypes as C
+    from bullet_amd import lib, parallel
+    comm = parallel.Comm.rccl()
+    try:
+        L = lib.load()
+        assert L.bt_comm_rank(comm.h) == 0 and L.bt_comm_world(comm.h) == 1
+        x = torch.arange(4096, dtype=torch.float32, device="cuda") * 0.5
+        want = x.clone()
+        comm.all_reduce(x)
+        s = torch.cuda.current_stream().cuda_stream
+        y = torch.zeros_like(x)
+        lib.check(L.bt_reduce_scatter_sum_f32(comm.h, s, x.data_ptr(), y.data_ptr(), x.numel()))
+        z = torch.zeros_like(x)
+        lib.check(L.bt_allgather_f32(comm.h, s, y.data_ptr(), z.data_ptr(), x.numel()))
+        lib.check(L.bt_allreduce_sum_f32(comm.h, s, z.data_ptr(), 0))  # empty: accepted, nothing sent
+        torch.cuda.synchronize()
+        assert torch.equal(x, want) and torch.equal(y, want) and torch.equal(z, want)
+        ref = _run(None, True, "multi", "sharded")
+        for mode in ("comm", "sharded"):
+            got = _run(None, True, "multi", mode, comm=comm)
+            assert got[0] == ref[0] and got[1] == ref[1]
+            assert np.array_equal(got[2], ref[2][:got[2].size])
+    finally:
+        comm.close()
