@@ -3,9 +3,12 @@
 
 Workload = BASELINE.json configs[1]: Chess768 -> 1024x2 SCReLU -> 1 with 8 output buckets,
 batch 16384 per GPU, AdamW; one "step" = fwd + bwd (+ gradient all-reduce when N > 1) + AdamW
-over one batch of synthetic positions that is already resident in HBM.
-N > 1: one process per GPU (torchrun), data parallel, gradients all-reduced with RCCL, weak scaling
-(per-GPU batch fixed at 16384, global batch 16384*N, adj = 1/global batch as run.rs:130 does).
+over one batch of synthetic positions that is already resident in HBM, with the pinned-host -> HBM upload of the NEXT
+batch running beside it on a copy stream (inside the timed loop).
+N > 1: one process per GPU (torchrun), data parallel through the library's own RCCL communicator (bt_comm).
+`value` is the contract metric of SURVEY.md 8d -- the GLOBAL batch of 16384 split over the GPUs (strong scaling) --
+and a `weak` sub-record (16384 per GPU) is printed beside it, each with ms/step and the time of the exchange alone.
+At N = 1 the line also carries `fixture_occupancy` (the same net at the fixture's piece counts) and `halfka` (--net cfg3).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
 kernel (timed live with HIP events on the kernels' own stream) and `cpu_baseline` (the CPU oracle,
@@ -128,26 +131,265 @@ def algorithmic_bytes(kernel, B, nbar, P=2, H=1024, N=32, F=768, K=2048, O=8):
     return table.get(kernel)
 
 
+def roofline_record(dom, c, ms, sample, steps, B, nbar, netcfg, step_s, traffic_tab):
+    """The dominant kernel against the bound that applies to it. ALGORITHMIC bytes per launch over the
+    kernel's average launch time, measured live with HIP events on the kernel's own stream. The feature-transformer
+    kernels keep their table tile in LDS, so those bytes are LDS gathers and the bound is the LDS array (~150 TB/s
+    chip-wide, MI355X_MICROARCH.md); `hbm_frac` is the counter-measured HBM traffic of the same kernel against
+    8 TB/s, and `algorithmic_vs_hbm` the 8d figure against 8 TB/s -- a ratio, not a fraction: it exceeds 1 when the
+    table never leaves the chip."""
+    abytes = algorithmic_bytes(dom, B, nbar, H=netcfg["ft_out"], F=netcfg["num_inputs"],
+                               K=netcfg["ft_out"] * (1 if netcfg.get("pairwise") else 2),
+                               O=netcfg["dense"][0][0] * netcfg["num_buckets"])
+    if not abytes or c == 0:
+        return None
+    launches_per_step = max(1.0, round(c * sample / steps))
+    avg_s = ms / c * 1e-3
+    per_launch = abytes / launches_per_step
+    ach = per_launch / avg_s / 1e9
+    entry = next((v for k, v in traffic_tab.items() if isinstance(v, dict) and v.get("bench_id", k) == dom), None)
+    measured_batch = (traffic_tab.get("_step") or {}).get("batch", 16384)  # the counters were collected at this batch
+    if B != measured_batch:
+        entry, traffic_tab = None, {}
+    traffic = entry.get("hbm_bytes_per_launch") if entry else None
+    lds = dom in ("ft_fwd_lds", "ft_bwd_lds")
+    peak = LDS_PEAK_GBS if lds else HBM_PEAK_GBS
+    rec = {"kernel": (entry or {}).get("kernel", dom), "bound": "lds" if lds else "hbm", "achieved": ach, "peak": peak,
+           "unit": "GB/s", "frac": ach / peak, "traffic": traffic,
+           "hbm_frac": (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+           "algorithmic_vs_hbm": ach / HBM_PEAK_GBS,
+           "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": per_launch, "timed_launches": c}
+    step = traffic_tab.get("_step") or {}
+    if step.get("hbm_bytes_per_step"):
+        rec["hbm_bytes_per_step"] = step["hbm_bytes_per_step"]
+        rec["hbm_step_frac"] = step["hbm_bytes_per_step"] / step_s / 1e9 / HBM_PEAK_GBS
+    return rec
+
+
+def traffic_table(net_name):
+    """HBM bytes per launch from the rocprofv3 PMC passes (profiles/README.md says how they are collected)"""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json" if net_name == "cfg2" else f"hbm_traffic_{net_name}.json")
+    return json.load(open(path)) if os.path.exists(path) else {}
+
+
+def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warmup, records=None):
+    """One workload on this rank: warm-up (with the per-kernel table), then `steps` timed steps. A step = upload of the
+    NEXT batch from pinned host memory on a copy stream (one packed buffer per batch, overlapped) + fwd + bwd +
+    gradient exchange (N > 1) + optimiser over the batch already in HBM."""
+    import torch
+    from bullet_amd import lib, parallel
+    L = lib.load()
+    n_distinct = 4  # distinct batches, rotated
+    netcfg, input_kind, layout, workload = NETS[net_name]
+    idesc = lib.make_input_desc(input_kind, False, layout)
+    nnz = netcfg["nnz"]
+    words = B * (2 * nnz + 3)  # stm, nstm, buckets, targets, weights: 4-byte words of one batch
+    host_packs, nbar, first = [], 0.0, None
+    for i in range(n_distinct):
+        if records:
+            allrec = np.fromfile(records, dtype=np.uint8).reshape(-1, 32)
+            rec = allrec[(np.arange(B) + i * B) % allrec.shape[0]].reshape(-1).copy()
+        else:
+            rec = synth_records(B, 0xB011E7000 + 2 + 1000 * (rank * n_distinct + i), occupancy)
+        mapped = lib.map_batch(idesc, rec, out_buckets=8, blend=0.75, eval_scale=400.0, threads=8)
+        stm = mapped[0]
+        nbar += np.where((stm < 0).any(1), (stm < 0).argmax(1), nnz).mean() / n_distinct
+        first = first or mapped
+        # pinned staging straight from the runtime (bt_host_alloc_pinned), filled once: stm | nstm | buckets | targets | weights
+        hp = C.c_void_p()
+        if args.upload == "records":  # the 32-byte records themselves; bt_map_batch_device maps them behind the copy
+            lib.check(L.bt_host_alloc_pinned(C.byref(hp), B * 32))
+            np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_uint8)), shape=(B * 32,))[:] = rec
+        else:
+            lib.check(L.bt_host_alloc_pinned(C.byref(hp), words * 4))
+            np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_int32)), shape=(words,))[:] = \
+                np.concatenate([a.reshape(-1).view(np.int32) for a in mapped])
+        host_packs.append(hp)
+
+    net = lib.Net(lib.make_net_desc(**netcfg), B)
+    if net_name == "cfg2":  # random-init weights of the architecture: Normal(0, sqrt(2/in)), same on all ranks
+        rng = np.random.default_rng(1234)
+        init = []
+        for t, n in enumerate(net.sizes):
+            fan_in = 768 if t == 0 else 2048
+            init.append(np.zeros(n, np.float32) if t & 1 else (rng.standard_normal(n) * np.sqrt(2.0 / fan_in)).astype(np.float32))
+        net.set_params(init)
+    else:
+        net.init_weights(ft_effective_inputs=32)  # the reference's stream and init_with_effective_input_size(32)
+
+    def views(pack):
+        o, out = 0, []
+        for n, dt in ((B * nnz, torch.int32), (B * nnz, torch.int32), (B, torch.int32), (B, torch.float32), (B, torch.float32)):
+            out.append(pack[o:o + n].view(dt).view(B, nnz) if n == B * nnz else pack[o:o + n].view(dt))
+            o += n
+        return out
+
+    SETS = 3  # device batch sets: one in use, one being filled, one spare (see step())
+    dev_packs = [torch.empty(words, dtype=torch.int32, device="cuda") for _ in range(SETS)]
+    dev_batches = [net.make_batch(*views(p)) for p in dev_packs]
+    dev_ptrs = [p.data_ptr() for p in dev_packs]
+    dev_views = [[t.data_ptr() for t in views(p)] for p in dev_packs]
+    dev_records = [torch.empty(B * 32, dtype=torch.uint8, device="cuda") for _ in range(SETS)]
+    mopts = lib.MapOpts(8, 0.75, 400.0, 0, 0, 1)
+
+    def handle(create):
+        h = C.c_void_p()
+        lib.check(create(C.byref(h)))
+        return h
+
+    # copy stream + events through the C ABI (a torch copy_ from pinned memory costs ~0.1 ms of HOST time per call on
+    # ROCm -- the pointer-attribute query -- which would make the loop host-bound)
+    uploaded = [handle(L.bt_event_create) for _ in range(SETS)]
+    consumed = [handle(L.bt_event_create) for _ in range(SETS)]
+    copy = handle(L.bt_stream_create)
+    X = os.environ.get("BENCH_X", "").split(",")  # "devwait": the experiment described in step()
+    stream = torch.cuda.current_stream().cuda_stream
+    adj = torch.tensor([parallel.adj_factor(global_batch)], device="cuda")
+    lr = torch.tensor([1e-3], device="cuda")
+    multi_layer = net_name != "cfg2"
+    nbytes = words * 4
+
+    def upload(k, dst, on):
+        """batch k of the rotation into device set `dst`, in `on` stream order"""
+        if args.upload == "records":
+            lib.check(L.bt_memcpy_h2d_async(dev_records[dst].data_ptr(), host_packs[k], B * 32, on))
+            lib.check(L.bt_map_batch_device(on, C.byref(idesc), C.byref(mopts), dev_records[dst].data_ptr(), B, *dev_views[dst]))
+        else:
+            lib.check(L.bt_memcpy_h2d_async(dev_ptrs[dst], host_packs[k], nbytes, on))
+
+    if args.upload == "none":  # (an experiment, not the contract: the sets are resident, nothing moves)
+        for k in range(SETS):
+            lib.check(L.bt_memcpy_h2d_async(dev_ptrs[k], host_packs[k], nbytes, stream))
+    else:
+        upload(0, 0, stream)
+    lib.check(L.bt_event_record(uploaded[0], stream))
+    counter = [0]
+
+    def step():
+        i = counter[0]
+        counter[0] += 1
+        cur, nxt = i % SETS, (i + 1) % SETS
+        if args.upload != "none":
+            # The set being filled was last read two steps ago. The HOST waits for that step (it then runs at most two
+            # steps ahead of the GPU, which always has a full step queued); a device-side wait of the copy stream on the
+            # compute stream instead costs ~0.12 ms per step here: the copy then starts late enough to stall the
+            # step after it (tools/step_timeline_copies.sh).
+            if i >= 2:
+                if "devwait" in X:
+                    L.bt_stream_wait_event(copy, consumed[nxt])
+                else:
+                    L.bt_event_sync(consumed[nxt])
+            upload((i + 1) % n_distinct, nxt, copy)
+            L.bt_event_record(uploaded[nxt], copy)
+        if multi_layer:  # its index structures are built during this step, once the upload has landed
+            net.hint_next(dev_batches[nxt], uploaded[nxt] if args.upload != "none" else None)
+        if args.upload != "none":
+            L.bt_stream_wait_event(stream, uploaded[cur])
+        net.forward_backward(dev_batches[cur], stream)
+        if comm is not None:
+            net.dp_step(comm, adj, lr, stream)  # exchange (grads + loss slot) and optimiser, replicas stay identical
+        else:
+            net.optimiser_step(adj, lr, stream)
+        L.bt_event_record(consumed[cur], stream)
+
+    def release():
+        torch.cuda.synchronize()
+        lib.check(L.bt_stream_sync(copy))
+        for e in uploaded + consumed:
+            L.bt_event_destroy(e)
+        L.bt_stream_destroy(copy)
+        for hp in host_packs:
+            L.bt_host_free_pinned(hp)
+        net.close()
+
+    # Per-kernel HIP-event timing costs ~20 % of a 0.25 ms step when every kernel is timed, so the full per-kernel
+    # table is taken over the warm-up steps and the timed region times only the dominant kernel -- and only every
+    # SAMPLE-th launch of it. The average over the samples agrees with the rocprofv3 kernel trace (profiles/README.md).
+    profile = not args.no_profile
+    if profile and warmup > 0:
+        lib.profile_start(warmup * 24 + 64)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    warm = lib.profile_stop() if (profile and warmup > 0) else {}
+    # side-stream kernels overlap the main stream and never gate the step: the dominant kernel is looked for among
+    # the feature-transformer passes (>= 85 % of the critical path)
+    cand = {k: v for k, v in warm.items() if k.startswith("ft_") and k != "ft_index_kernel"} or \
+           {k: v for k, v in warm.items() if k != "ft_index_kernel"}
+    dom = max(cand, key=lambda k: cand[k][1]) if cand else None
+    SAMPLE = 8
+    if comm is not None:
+        comm.barrier()
+    if profile and dom:
+        lib.profile_start(steps * 2 + 64, only=[dom], every=SAMPLE)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if comm is not None:
+        comm.barrier()
+    elapsed = time.perf_counter() - t0
+    kern = lib.profile_stop() if (profile and dom) else {}
+    res = {"elapsed": elapsed, "loss": net.loss.item() / global_batch, "nbar": float(nbar), "warm": warm, "dom": dom,
+           "kern": kern.get(dom) if dom else None, "sample": SAMPLE, "netcfg": netcfg, "workload": workload,
+           "first_batch": first, "net": net, "idesc": idesc, "release": release}
+    if comm is not None and comm.world > 1:  # the exchange alone, same buffers, back to back
+        reps = 50
+        torch.cuda.synchronize()
+        comm.barrier()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            comm.all_reduce(net.step_buffer)
+        torch.cuda.synchronize()
+        res["allreduce_us"] = (time.perf_counter() - t1) / reps * 1e6
+        res["allreduce_bytes"] = net.step_buffer.numel() * 4
+    return res
+
+
+def case_record(res, B, global_batch, steps, warmup, net_name, with_kernels=True):
+    """the part of the JSON line one run_case contributes"""
+    ms = res["elapsed"] / steps * 1e3
+    out = {"value": global_batch * steps / res["elapsed"], "unit": "positions/sec", "ms_per_step": ms,
+           "batch_per_gpu": B, "global_batch": global_batch, "mean_active_features": round(res["nbar"], 2),
+           "final_loss": res["loss"]}
+    if "allreduce_us" in res:
+        out["allreduce_us"], out["allreduce_bytes"] = res["allreduce_us"], res["allreduce_bytes"]
+    if with_kernels and res["warm"]:
+        out["kernels_us_per_step_warmup"] = {k: round(1e3 * t / warmup, 2) for k, (c, t) in res["warm"].items()}
+    if res["kern"]:
+        c, t = res["kern"]
+        rl = roofline_record(res["dom"], c, t, res["sample"], steps, B, res["nbar"], res["netcfg"],
+                             res["elapsed"] / steps, traffic_table(net_name))
+        if rl:
+            out["roofline"] = rl
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=16384, help="positions per GPU per step")
+    ap.add_argument("--batch", type=int, default=16384, help="the GLOBAL batch (every example of the reference: 16384)")
     ap.add_argument("--occupancy", choices=["full", "fixture"], default="full",
                     help="pieces per synthetic position: 32 (worst case) or the batch.bf histogram (mean 16.2)")
     ap.add_argument("--records", default=None, metavar="FILE.bf",
                     help="take positions from a bulletformat file (tiled to the batch size) instead of the synthetic "
                          "generator, e.g. tests/golden/batch.bf: real feature skew (not the contract workload)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: --batch positions per GPU (default); strong: --batch is the global batch, split over the GPUs")
     ap.add_argument("--net", choices=sorted(NETS), default="cfg2",
                     help="cfg2 = the contract workload (BASELINE configs[1]); cfg3 / cfg4 = the HalfKA multi-layer nets")
+    ap.add_argument("--upload", choices=["records", "mapped", "none"], default="records",
+                    help="what crosses PCIe for the next batch inside the timed loop: the 32-byte records (mapped on the "
+                         "device by bt_map_batch_device behind the copy; 32 B/position, the training loop's device_mapper "
+                         "path), the five mapped tensors (268 B/position), or nothing (an experiment, not the contract)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-subrecords", action="store_true",
+                    help="only the main workload: no fixture_occupancy / halfka (N = 1) or weak (N > 1) sub-records")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--live-loader", type=int, default=0, metavar="BATCHES",
-                    help="also time bt_train_run (file reader + threaded mapper + pinned H2D + step) over this many "
-                         "batches and report it as `live_loader` (not part of `value`)")
+                    help="also time bt_train_run (file reader + mapper + pinned H2D + step) over this many batches and "
+                         "report it as `live_loader` (not part of `value`)")
     ap.add_argument("--loader-threads", type=int, default=16)
     ap.add_argument("--host-mapper", action="store_true",
                     help="--live-loader with the threaded host mapper instead of the device mapper")
@@ -162,166 +404,97 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
-    dist = None
+    dist = comm = None
     if world > 1:
         import torch.distributed as dist
-        # nccl == RCCL on ROCm. BULLET_AMD_DIST_BACKEND=gloo rehearses the N > 1 path with several ranks on ONE GPU
-        # (RCCL wants a GPU per rank): same code path, the collective staged through the host.
+        # torch.distributed is the launcher's rendezvous (it carries the RCCL id and the final max-over-ranks); the
+        # step's collectives are the library's own RCCL communicator. BULLET_AMD_DIST_BACKEND=gloo rehearses the N > 1
+        # path with several ranks on ONE GPU (RCCL wants a GPU per rank): hooks, staged through the host.
         backend = os.environ.get("BULLET_AMD_DIST_BACKEND", "nccl")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            comm = parallel.Comm.rccl(dist)
         else:
             dist.init_process_group(backend)
+            comm = parallel.Comm.from_torch(dist)
+    lib.load()
 
-    L = lib.load()
-    if args.scaling == "strong":  # the reference's fixed global batch, contiguous shards (parallel.shard_range)
-        lo, hi = parallel.shard_range(args.batch, rank, world)
-        B, global_batch = hi - lo, args.batch
-    else:
-        B = args.batch
-        global_batch = B * world
-    n_distinct = 4  # distinct resident batches, rotated
-    netcfg, input_kind, layout, workload = NETS[args.net]
-    idesc = lib.make_input_desc(input_kind, False, layout)
-    batches, nbar = [], 0.0
-    for i in range(n_distinct):
-        if args.records:
-            allrec = np.fromfile(args.records, dtype=np.uint8).reshape(-1, 32)
-            rec = allrec[(np.arange(B) + i * B) % allrec.shape[0]].reshape(-1).copy()
-        else:
-            rec = synth_records(B, 0xB011E7000 + 2 + 1000 * (rank * n_distinct + i), args.occupancy)
-        stm, ntm, bk, tg, w = lib.map_batch(idesc, rec, out_buckets=8, blend=0.75, eval_scale=400.0, threads=8)
-        cnt = np.where((stm < 0).any(1), (stm < 0).argmax(1), 32)
-        nbar += cnt.mean() / n_distinct
-        batches.append((stm, ntm, bk, tg, w))
+    def tmax(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item()
 
-    desc = lib.make_net_desc(**netcfg)
-    net = lib.Net(desc, B)
-    # random-init weights of the architecture: Normal(0, sqrt(2/in)) from a fixed stream, same on all ranks
-    if args.net == "cfg2":
-        rng = np.random.default_rng(1234)
-        init = []
-        for t, n in enumerate(net.sizes):
-            fan_in = 768 if t == 0 else 2048
-            init.append(np.zeros(n, np.float32) if t & 1 else (rng.standard_normal(n) * np.sqrt(2.0 / fan_in)).astype(np.float32))
-        net.set_params(init)
-    else:
-        net.init_weights(ft_effective_inputs=32)  # the reference's stream and init_with_effective_input_size(32)
-    dev_batches = []
-    for stm, ntm, bk, tg, w in batches:
-        t = [torch.from_numpy(a).cuda() for a in (stm, ntm, bk, tg, w)]
-        dev_batches.append(net.make_batch(*t))
-    adj = torch.tensor([parallel.adj_factor(global_batch)], device="cuda")
-    lr = torch.tensor([1e-3], device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
-
-    multi_layer = args.net != "cfg2"
-
-    def step(i):
-        if multi_layer:  # the next batch is resident: its index structures are built during this step
-            net.hint_next(dev_batches[(i + 1) % n_distinct])
-        net.forward_backward(dev_batches[i % n_distinct], stream)
-        parallel.allreduce_step_buffers(dist, net.step_buffer)  # grads + loss, one collective; replicas stay identical
-        net.optimiser_step(adj, lr, stream)
-
-    # Per-kernel HIP-event timing costs ~20 % of a 0.4 ms step when every kernel is timed, so the full per-kernel
-    # table is taken over the warm-up steps and the timed region times only the dominant kernel -- and only every
-    # SAMPLE-th launch of it: a timed launch (timestamps on its dispatch packet) costs the stream ~10 us, 4 % of a
-    # 0.26 ms step. The average over the samples agrees with the rocprofv3 kernel trace (profiles/README.md).
-    profile = not args.no_profile
-    if profile and args.warmup > 0:
-        lib.profile_start(args.warmup * 16 + 64)
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    warm = lib.profile_stop() if (profile and args.warmup > 0) else {}
-    # side-stream kernels overlap the main stream and never gate the step
-    # (and the brackets of the small kernels that follow a stream join absorb the wait for the other stream: the
-    # dominant kernel is looked for among the feature-transformer passes, which are >= 85 % of the critical path)
-    cand = {k: v for k, v in warm.items() if k.startswith("ft_") and k != "ft_index_kernel"} or \
-           {k: v for k, v in warm.items() if k != "ft_index_kernel"}
-    dom = max(cand, key=lambda k: cand[k][1]) if cand else None
-    if dist is not None:
-        dist.barrier()
-    SAMPLE = 8
-    if profile and dom:
-        lib.profile_start(args.steps * 2 + 64, only=[dom], every=SAMPLE)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    kern = lib.profile_stop() if (profile and dom) else {}
-    loss_per_pos = net.loss.item() / global_batch
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = tmax.item()
-
+    # the contract metric: fixed GLOBAL batch, split into contiguous shards over the GPUs
+    lo, hi = parallel.shard_range(args.batch, rank, world)
+    B = hi - lo
+    main_res = run_case(args, args.net, args.occupancy, B, args.batch, rank, comm, args.steps, args.warmup, args.records)
+    main_res["elapsed"] = tmax(main_res["elapsed"])
+    out = None
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = global_batch * args.steps / elapsed
+        rec = case_record(main_res, B, args.batch, args.steps, args.warmup, args.net)
         out = {
             "metric": "training positions/sec (whole node) HalfKA-1024 SCReLU net at 1/2/4/8 GPUs",
-            "value": value, "unit": "positions/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic" if not args.records else "file:" + os.path.basename(args.records),
-            "config": {"workload": workload, "batch_per_gpu": B, "global_batch": global_batch,
-                       "occupancy": args.occupancy, "mean_active_features": round(float(nbar), 2),
-                       "parallelism": f"dp{world}"},
-            "final_loss": loss_per_pos,
+            "value": rec["value"], "unit": "positions/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if not args.records else "file:" + os.path.basename(args.records),
+            "config": {"workload": main_res["workload"], "batch_per_gpu": B, "global_batch": args.batch,
+                       "occupancy": args.occupancy, "mean_active_features": rec["mean_active_features"],
+                       "parallelism": f"dp{world}",
+                       "upload": args.upload,
+                       "step": "pinned-host -> HBM upload of the next batch (copy stream"
+                               + (", 32-byte records + bt_map_batch_device" if args.upload == "records" else "")
+                               + ") || fwd + bwd"
+                               + (" + RCCL gradient exchange" if world > 1 else "") + " + AdamW"},
+            "final_loss": rec["final_loss"],
         }
-        if warm:
-            out["kernels_us_per_step_warmup"] = {k: round(1e3 * ms / args.warmup, 2) for k, (c, ms) in warm.items()}
-        if kern:
-            c, ms = kern[dom]
-            abytes = algorithmic_bytes(dom, B, nbar, H=netcfg["ft_out"], F=netcfg["num_inputs"],
-                                       K=netcfg["ft_out"] * (1 if netcfg.get("pairwise") else 2),
-                                       O=netcfg["dense"][0][0] * netcfg["num_buckets"])
-            launches_per_step = max(1.0, round(c * SAMPLE / args.steps))
-            avg_s = ms / c * 1e-3
-            traffic = None
-            # PMC passes, see profiles/README.md (cfg2: profiles/hbm_traffic.json; the HalfKA nets: r01_cfg3/)
-            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json" if args.net == "cfg2"
-                                 else f"r01_cfg3/hbm_traffic_{args.net}.json")
-            if os.path.exists(tpath):
-                tab = json.load(open(tpath))
-                traffic = (tab.get(dom + "_any") or tab.get(dom) or {}).get("hbm_bytes_per_launch")
-            if abytes:
-                per_launch = abytes / max(launches_per_step, 1.0)
-                ach = per_launch / avg_s / 1e9
-                out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                                   "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": per_launch,
-                                   "timed_launches": c}
-                if dom in ("ft_fwd_lds", "ft_bwd_lds"):
-                    # The table tile lives in LDS, so the algorithmic bytes are LDS gathers, not HBM reads (frac > 1
-                    # against HBM is expected). The bound that applies is the LDS array: ~150 TB/s chip-wide
-                    # for ds_read_b128 (MI355X_MICROARCH.md, LDS section), 2/3 of that with the unavoidable
-                    # two-random-rows-per-256-B-line conflicts.
-                    out["roofline"]["lds"] = {"achieved": ach, "peak": LDS_PEAK_GBS, "unit": "GB/s",
-                                              "frac": ach / LDS_PEAK_GBS}
-        if args.live_loader > 0 and world == 1:
-            import tempfile
-            with tempfile.TemporaryDirectory() as td:
-                path = os.path.join(td, "synthetic.bf")
-                synth_records(B * 8, 0xB011E7000 + 99, args.occupancy).tofile(path)
-                nb = args.live_loader
-                assert args.net == "cfg2", "--live-loader is wired for the contract workload"
-                rep = net.train(idesc, [path], B, nb, 2, lib.LrSched(lib.LR["constant"], 1e-3, 0, 0, 0),
-                                lib.WdlSched(lib.WDL["constant"], 0.75, 0, 0), out_buckets=8, threads=args.loader_threads,
-                                device_mapper=not args.host_mapper)
-                out["live_loader"] = {"positions_per_sec": rep[-1][2], "batches": nb, "threads": args.loader_threads,
-                                      "mapper": "host" if args.host_mapper else "device",
-                                      "note": "second superbatch of bt_train_run: reader + mapper + H2D + step"}
+        for k in ("kernels_us_per_step_warmup", "roofline", "allreduce_us", "allreduce_bytes"):
+            if k in rec:
+                out[k] = rec[k]
+    if args.live_loader > 0 and world == 1:
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "synthetic.bf")
+            synth_records(B * 8, 0xB011E7000 + 99, args.occupancy).tofile(path)
+            nb = args.live_loader
+            assert args.net == "cfg2", "--live-loader is wired for the contract workload"
+            rep = main_res["net"].train(main_res["idesc"], [path], B, nb, 2, lib.LrSched(lib.LR["constant"], 1e-3, 0, 0, 0),
+                                        lib.WdlSched(lib.WDL["constant"], 0.75, 0, 0), out_buckets=8,
+                                        threads=args.loader_threads, device_mapper=not args.host_mapper)
+            out["live_loader"] = {"positions_per_sec": rep[-1][2], "batches": nb, "threads": args.loader_threads,
+                                  "mapper": "host" if args.host_mapper else "device",
+                                  "note": "second superbatch of bt_train_run: reader + mapper + H2D + step"}
+    first_batch = main_res["first_batch"]
+    main_res["release"]()
+    del main_res
+
+    if not args.no_subrecords and not args.records:
+        if world == 1:
+            # the same contract workload at the fixture's piece counts, and the HalfKA-1024 net the metric is named for
+            for key, net_name, occ in (("fixture_occupancy", args.net, "fixture"), ("halfka", "cfg3", "full")):
+                if (net_name, occ) == (args.net, args.occupancy):
+                    continue
+                r = run_case(args, net_name, occ, B, args.batch, rank, None, args.steps, args.warmup)
+                sub = case_record(r, B, args.batch, args.steps, args.warmup, net_name)
+                sub["workload"], sub["occupancy"] = r["workload"], occ
+                out[key] = sub
+                r["release"]()
+        else:
+            # weak scaling beside it: the full batch on every GPU (global batch = N x 16384)
+            r = run_case(args, args.net, args.occupancy, args.batch, args.batch * world, rank, comm, args.steps, args.warmup)
+            r["elapsed"] = tmax(r["elapsed"])
+            if rank == 0:
+                out["weak"] = case_record(r, args.batch, args.batch * world, args.steps, args.warmup, args.net, with_kernels=False)
+            r["release"]()
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1 and args.net == "cfg2":
-            out["cpu_baseline"] = cpu_baseline(batches[0], B)
+            out["cpu_baseline"] = cpu_baseline(first_batch, min(B, 16384))
         print(json.dumps(out))
-    net.close()
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.destroy_process_group()
 

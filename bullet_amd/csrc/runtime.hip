@@ -227,6 +227,38 @@ int bt_stream_sync(void *stream) {
     return BT_OK;
 }
 
+int bt_event_create(void **event) {
+    BT_REQUIRE(event, "bt_event_create: null argument");
+    hipEvent_t e;
+    BT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *event = e;
+    return BT_OK;
+}
+
+int bt_event_destroy(void *event) {
+    if (!event) return BT_OK;
+    BT_HIP(hipEventDestroy(static_cast<hipEvent_t>(event)));
+    return BT_OK;
+}
+
+int bt_event_record(void *event, void *stream) {
+    BT_REQUIRE(event, "bt_event_record: null event");
+    BT_HIP(hipEventRecord(static_cast<hipEvent_t>(event), bt_stream(stream)));
+    return BT_OK;
+}
+
+int bt_event_sync(void *event) {
+    BT_REQUIRE(event, "bt_event_sync: null event");
+    BT_HIP(hipEventSynchronize(static_cast<hipEvent_t>(event)));
+    return BT_OK;
+}
+
+int bt_stream_wait_event(void *stream, void *event) {
+    BT_REQUIRE(event, "bt_stream_wait_event: null event");
+    BT_HIP(hipStreamWaitEvent(bt_stream(stream), static_cast<hipEvent_t>(event), 0));
+    return BT_OK;
+}
+
 int bt_memset_async(void *ptr, int byte_value, size_t bytes, void *stream) {
     if (bytes == 0) return BT_OK;
     BT_REQUIRE(ptr, "bt_memset_async: null pointer");

@@ -481,9 +481,13 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
 
     constexpr int RING = 4;
     HostSlot slots[RING];
-    DevSet dev[2];
+    // device batch sets: one being read by the step, one being filled, one spare -- the set a copy overwrites was
+    // last read TWO steps ago, and the host (never more than LOSS_RING - 1 steps ahead anyway) waits for that step
+    // itself. Making the copy stream wait for the compute stream on the device instead cost ~0.05-0.12 ms per step.
+    constexpr int SETS = 3;
+    DevSet dev[SETS];
     void *copy_stream = nullptr, *compute_stream = nullptr;
-    hipEvent_t uploaded[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr}, slot_copied[RING] = {nullptr};
+    hipEvent_t uploaded[SETS] = {nullptr}, consumed[SETS] = {nullptr}, slot_copied[RING] = {nullptr};
     constexpr int LOSS_RING = 4;
     hipEvent_t loss_ready[LOSS_RING] = {nullptr};
     float lr_slot[LOSS_RING] = {0.0f};
@@ -737,17 +741,17 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
     };
     int next_slot = -1;
     for (long long step = 0; step < total_steps; step++) {
-        const int set = (int)(step & 1);
+        const int set = (int)(step % SETS), nset = (int)((step + 1) % SETS);
         const int ring = (int)(step % LOSS_RING);
-        // next batch: upload into the other device set while this step computes (run.rs:194-207). It is enqueued
+        // next batch: upload into the following device set while this step computes (run.rs:194-207). It is enqueued
         // BEFORE this step, so that the net can be told about it (its index structures are then built during this
-        // step); the other set was last read by the step before this one (`consumed`).
+        // step); that set was last read by the step two before this one (`consumed`), which the host waits for.
         if (step + 1 < total_steps) {
             TRY(take_ready(&next_slot));
-            if (step >= 1) TRY_HIP(hipStreamWaitEvent(bt_stream(copy_stream), consumed[set ^ 1], 0));
-            TRY(upload(next_slot, set ^ 1));
-            const bt_batch nb = dev_batch(set ^ 1);
-            TRY(bt_net_hint_next_batch(net, &nb, uploaded[set ^ 1]));
+            if (step >= SETS - 1) TRY_HIP(hipEventSynchronize(consumed[nset]));
+            TRY(upload(next_slot, nset));
+            const bt_batch nb = dev_batch(nset);
+            TRY(bt_net_hint_next_batch(net, &nb, uploaded[nset]));
         }
         // compute waits for this batch's upload; the learning rate goes through a pinned ring (run.rs:171-173)
         TRY_HIP(hipStreamWaitEvent(bt_stream(compute_stream), uploaded[set], 0));

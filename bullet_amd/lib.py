@@ -141,6 +141,7 @@ SYMBOLS = [
     "bt_version", "bt_last_error",
     "bt_device_count", "bt_device_set", "bt_device_props", "bt_device_sync", "bt_malloc", "bt_free",
     "bt_host_alloc_pinned", "bt_host_free_pinned", "bt_stream_create", "bt_stream_destroy", "bt_stream_sync",
+    "bt_event_create", "bt_event_destroy", "bt_event_record", "bt_stream_wait_event", "bt_event_sync",
     "bt_memset_async", "bt_memcpy_h2d_async", "bt_memcpy_d2h_async", "bt_memcpy_d2d_async",
     "bt_profile_start", "bt_profile_set_filter", "bt_profile_set_sampling", "bt_profile_stop", "bt_profile_num_kernels", "bt_profile_kernel_name",
     "bt_ft_forward", "bt_ft_backward_workspace_bytes", "bt_ft_backward", "bt_ft_build_index",
@@ -196,6 +197,13 @@ def load():
     L.bt_host_alloc_pinned.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     L.bt_host_free_pinned.argtypes = [C.c_void_p]
     L.bt_stream_sync.argtypes = [C.c_void_p]
+    L.bt_stream_create.argtypes = [C.POINTER(C.c_void_p)]
+    L.bt_stream_destroy.argtypes = [C.c_void_p]
+    L.bt_event_create.argtypes = [C.POINTER(C.c_void_p)]
+    L.bt_event_destroy.argtypes = [C.c_void_p]
+    L.bt_event_record.argtypes = [C.c_void_p, C.c_void_p]
+    L.bt_event_sync.argtypes = [C.c_void_p]
+    L.bt_stream_wait_event.argtypes = [C.c_void_p, C.c_void_p]
     L.bt_memset_async.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
     for f in ("bt_memcpy_h2d_async", "bt_memcpy_d2h_async", "bt_memcpy_d2d_async"):
         getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -527,9 +535,20 @@ class Net:
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
         check(self.L.bt_net_forward_backward(self.h, s, C.byref(batch), self.loss.data_ptr()))
 
-    def hint_next(self, batch):
-        """bt_net_hint_next_batch: `batch` (device-resident, complete) is what the step after the coming one uses"""
-        check(self.L.bt_net_hint_next_batch(self.h, C.byref(batch) if batch is not None else None, None))
+    def hint_next(self, batch, ready=None):
+        """bt_net_hint_next_batch: `batch` is what the step after the coming one uses; its tensors are complete now, or
+        once `ready` (a recorded event: a hipEvent_t handle or a torch.cuda.Event) has fired"""
+        ev = None if ready is None else ready if isinstance(ready, (int, C.c_void_p)) else C.c_void_p(ready.cuda_event)
+        check(self.L.bt_net_hint_next_batch(self.h, C.byref(batch) if batch is not None else None, ev))
+
+    def dp_step(self, comm, adj_dev, lr_dev, stream=None, shard_min_floats=0):
+        """bt_net_dp_step: gradient exchange through `comm` (a parallel.Comm) + the optimiser step"""
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        rc = self.L.bt_net_dp_step(self.h, comm.h, s, adj_dev.data_ptr(), lr_dev.data_ptr(), shard_min_floats)
+        if comm.errors:
+            raise comm.errors[0]
+        check(rc)
 
     def optimiser_step(self, adj_dev, lr_dev, stream=None):
         import torch

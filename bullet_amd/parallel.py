@@ -57,7 +57,7 @@ class Comm:
     the two-ranks-on-one-GPU tests, where RCCL cannot run)."""
 
     def __init__(self, handle, rank, world, keep=()):
-        self.h, self.rank, self.world, self._keep, self.errors = handle, rank, world, keep, []
+        self.h, self.rank, self.world, self._keep, self.errors, self._token = handle, rank, world, keep, [], None
 
     @classmethod
     def rccl(cls, dist=None):
@@ -89,7 +89,8 @@ class Comm:
         def guarded(fn):
             def call(*a):
                 try:
-                    with torch.cuda.stream(torch.cuda.ExternalStream(a[-1])):
+                    # (the NULL stream arrives as None)
+                    with torch.cuda.stream(torch.cuda.ExternalStream(a[-1]) if a[-1] else torch.cuda.default_stream()):
                         fn(*a[1:-1])
                     return 0
                 except Exception as e:  # an exception must not unwind through the C frames
@@ -137,6 +138,14 @@ class Comm:
         from . import lib
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
         lib.check(lib.load().bt_allreduce_sum_f32(self.h, s, tensor.data_ptr(), tensor.numel()))
+
+    def barrier(self):
+        """every rank has reached this point (a 1-float all-reduce, waited for)"""
+        import torch
+        if self._token is None:
+            self._token = torch.zeros(1, device="cuda")
+        self.all_reduce(self._token)
+        torch.cuda.current_stream().synchronize()
 
     def close(self):
         if self.h:

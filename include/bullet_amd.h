@@ -70,6 +70,14 @@ int bt_host_free_pinned(void *ptr);
 int bt_stream_create(void **stream);
 int bt_stream_destroy(void *stream);
 int bt_stream_sync(void *stream);
+/* Events order one stream behind another without blocking the host (no counterpart in GpuBindings: the reference
+ * joins its copy and compute streams with stream_sync on the host, run.rs:194-221). An event is a hipEvent_t passed
+ * as void* (timing disabled). */
+int bt_event_create(void **event);
+int bt_event_destroy(void *event);
+int bt_event_record(void *event, void *stream);
+int bt_stream_wait_event(void *stream, void *event);
+int bt_event_sync(void *event); /* the host waits until the recorded work is done */
 /* stream_memset / stream_memcpy_h2d / stream_memcpy_d2h, bindings.rs:110-125 */
 int bt_memset_async(void *ptr, int byte_value, size_t bytes, void *stream);
 int bt_memcpy_h2d_async(void *dst, const void *src_host, size_t bytes, void *stream);

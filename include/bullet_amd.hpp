@@ -692,6 +692,13 @@ class ValueTrainer {
     void data_parallel(int rank, int world, GradSync sync, void *user) {
         dp_rank_ = rank, dp_world_ = world, dp_sync_ = sync, dp_user_ = user;
     }
+    // The same through the library's own RCCL communicator (bt_comm_unique_id on rank 0, the 128-byte id handed to the
+    // other ranks, bt_comm_init_rank on each with its GPU current): the loop then exchanges with bt_net_dp_step -- a
+    // large feature-transformer table reduce-scattered, stepped on 1/world of it per rank and all-gathered, the rest
+    // all-reduced -- and nothing but C++ runs on the step path.
+    void data_parallel(bt_comm *comm) {
+        dp_comm_ = comm, dp_rank_ = bt_comm_rank(comm), dp_world_ = bt_comm_world(comm), dp_sync_ = nullptr, dp_user_ = nullptr;
+    }
 
     // value.rs:141-211: superbatch loop, checkpoints every save_rate superbatches + at the end, log.txt
     template <class LR, class WDL, class Loader>
@@ -706,6 +713,7 @@ class ValueTrainer {
         cfg.out_buckets = out_buckets_, cfg.use_win_rate_model = win_rate_model_, cfg.threads = settings.threads;
         cfg.log_rate = 128, cfg.wdl_output = wdl_output_, cfg.device_mapper = 0;
         cfg.dp_rank = dp_rank_, cfg.dp_world = dp_world_, cfg.grad_sync = dp_sync_, cfg.grad_sync_user = dp_user_;
+        cfg.comm = dp_comm_;
         cfg.fn_user = this;
         if (wdl_adjust)
             cfg.blend_fn = [](void *u, const void *rec, float blend) -> float {
@@ -939,6 +947,7 @@ class ValueTrainer {
     int dp_rank_ = 0, dp_world_ = 1;
     GradSync dp_sync_ = nullptr;
     void *dp_user_ = nullptr;
+    bt_comm *dp_comm_ = nullptr;
 };
 
 inline void OptimiserHandle::reset_state() {

@@ -10,7 +10,11 @@ import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_hbm"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/hbm_traffic.json"
-KERNELS = ["ft_fwd_lds", "ft_index_kernel", "ft_bwd_lds", "ft_bwd_merge", "head_finish_kernel", "dense_fwd_small",
+# real kernel name -> the id bench.py's live HIP-event table files it under (when they differ)
+BENCH_ID = {"ft_bwd_oct": "ft_bwd_lds", "ft_index_oct_kernel": "ft_index_kernel", "ft_bwd_merge_head": "ft_bwd_merge",
+            "ft_bwd_lds_any": "ft_bwd_lds", "ft_bwd_merge_grp": "ft_bwd_merge"}
+KERNELS = ["ft_fwd_lds", "ft_index_kernel", "ft_index_oct_kernel", "ft_bwd_oct", "ft_bwd_merge_head", "map_batch_kernel",
+           "ft_bwd_lds", "ft_bwd_merge", "head_finish_kernel", "dense_fwd_small",
            "dense_bwd_small_light", "dense_bwd_small", "sum_partials_seq4_kernel", "sum_partials4_kernel", "adamw_kernel",
            # the HalfKA multi-layer nets (bench.py --net cfg3 / cfg4)
            "ft_bwd_lds_any", "ft_bwd_merge_grp", "ft_group_count", "ft_group_scan", "ft_group_place", "bucket_perm_kernel",
@@ -27,15 +31,21 @@ def avg(path, counter):
             if k + "<" in r["Kernel_Name"] or k + "(" in r["Kernel_Name"]:
                 acc[k] += float(r["Counter_Value"])
                 n[k] += 1
-    return {k: acc[k] / n[k] for k in acc}
+    return {k: acc[k] / n[k] for k in acc}, n
 
 
-f, w = avg(f"{src}/FETCH_SIZE.csv", "FETCH_SIZE"), avg(f"{src}/WRITE_SIZE.csv", "WRITE_SIZE")
+(f, nf), (w, _) = avg(f"{src}/FETCH_SIZE.csv", "FETCH_SIZE"), avg(f"{src}/WRITE_SIZE.csv", "WRITE_SIZE")
 out = {"_comment": __doc__.strip().replace("\n", " ")}
+steps = max(nf.get("ft_fwd_lds", 0), 1)  # one forward launch per step
+total = 0.0
 for k in KERNELS:
     if k in f and k in w:
-        name = k
-        out[name] = {"FETCH_SIZE_KB": round(f[k], 1), "WRITE_SIZE_KB": round(w[k], 1),
-                     "hbm_bytes_per_launch": round((2 * f[k] + w[k]) * 1024, 1)}
+        per_launch = (2 * f[k] + w[k]) * 1024
+        out[k] = {"kernel": k, "bench_id": BENCH_ID.get(k, k), "FETCH_SIZE_KB": round(f[k], 1), "WRITE_SIZE_KB": round(w[k], 1),
+                  "hbm_bytes_per_launch": round(per_launch, 1), "launches_per_step": round(nf[k] / steps, 3)}
+        total += per_launch * nf[k] / steps
+# uploads of the next batch are copies, not kernels: B * (2 N + 3) * 4 bytes written per step, not in the counters
+out["_step"] = {"hbm_bytes_per_step": round(total, 1), "steps_profiled": steps,
+                "note": "sum over the kernels above of hbm_bytes_per_launch * launches_per_step (all streams)"}
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
