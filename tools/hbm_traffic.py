@@ -41,11 +41,13 @@ total = 0.0
 for k in KERNELS:
     if k in f and k in w:
         per_launch = (2 * f[k] + w[k]) * 1024
+        lps = nf[k] / steps
+        lps = float(round(lps)) if abs(lps - round(lps)) < 0.2 and round(lps) >= 1 else lps  # (+1 launch: the first upload)
         out[k] = {"kernel": k, "bench_id": BENCH_ID.get(k, k), "FETCH_SIZE_KB": round(f[k], 1), "WRITE_SIZE_KB": round(w[k], 1),
-                  "hbm_bytes_per_launch": round(per_launch, 1), "launches_per_step": round(nf[k] / steps, 3)}
-        total += per_launch * nf[k] / steps
+                  "hbm_bytes_per_launch": round(per_launch, 1), "launches_per_step": round(lps, 3)}
+        total += per_launch * lps
 # uploads of the next batch are copies, not kernels: B * (2 N + 3) * 4 bytes written per step, not in the counters
-out["_step"] = {"hbm_bytes_per_step": round(total, 1), "steps_profiled": steps,
+out["_step"] = {"hbm_bytes_per_step": round(total, 1), "steps_profiled": steps, "batch": 16384,
                 "note": "sum over the kernels above of hbm_bytes_per_launch * launches_per_step (all streams)"}
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
