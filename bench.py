@@ -246,7 +246,7 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
     stream = torch.cuda.current_stream().cuda_stream
     adj = torch.tensor([parallel.adj_factor(global_batch)], device="cuda")
     lr = torch.tensor([1e-3], device="cuda")
-    multi_layer = net_name != "cfg2"
+    multi_layer = net_name != "cfg2" and not args.no_hints
     nbytes = words * 4
 
     def upload(k, dst, on):
@@ -383,6 +383,9 @@ def main():
                     help="what crosses PCIe for the next batch inside the timed loop: the 32-byte records (mapped on the "
                          "device by bt_map_batch_device behind the copy; 32 B/position, the training loop's device_mapper "
                          "path), the five mapped tensors (268 B/position), or nothing (an experiment, not the contract)")
+    ap.add_argument("--no-hints", action="store_true",
+                    help="multi-layer nets: do not announce the next batch (bt_net_hint_next_batch), so its index "
+                         "structures are built on the step's own critical path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-subrecords", action="store_true",
                     help="only the main workload: no fixture_occupancy / halfka (N = 1) or weak (N > 1) sub-records")

@@ -182,77 +182,29 @@ __global__ __launch_bounds__(GRP_BLOCK) void ft_group_count(const int32_t *__res
     if ((int)threadIdx.x < nseg) blk_cnt[(size_t)blockIdx.x * nseg + threadIdx.x] = hist[threadIdx.x];
 }
 
-// pass 2 (one workgroup): exclusive scan in (segment major, block minor) order -> blk_cnt becomes each block's
-// write cursor per segment; chunk / item tables
-__global__ __launch_bounds__(256) void ft_group_scan(int *__restrict__ blk_cnt, int nblk, int nseg, int fwd_item,
-                                                     int g_ch, int4 *__restrict__ chunks, int4 *__restrict__ fitems,
-                                                     int4 *__restrict__ bitems, int *__restrict__ seg_items,
-                                                     int *__restrict__ counts) {
-    extern __shared__ __align__(16) int gl[];  // [nblk][nseg] counts -> exclusive prefixes
-    __shared__ int tot[256], seg_start[257], ch_start[257], fi_start[257], bi_start[257];
-    __shared__ int fi_per[256], bi_per[256];  // a segment's items are equal shares (in passes of 128 entries / chunks)
-    for (int i = threadIdx.x; i < nblk * nseg; i += blockDim.x) gl[i] = blk_cnt[i];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    for (int sg = wave; sg < nseg; sg += nwaves) {
-        int run = 0;
-        for (int b0 = 0; b0 < nblk; b0 += 64) {
-            const int b = b0 + lane;
-            const int v = b < nblk ? gl[b * nseg + sg] : 0;
-            int incl = v;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int up = __shfl_up(incl, o);
-                if (lane >= o) incl += up;
-            }
-            if (b < nblk) gl[b * nseg + sg] = run + incl - v;
-            run += __shfl(incl, 63);
-        }
-        if (lane == 0) tot[sg] = run;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int a = 0, c = 0, f = 0, bi = 0;
-        for (int sg = 0; sg < nseg; sg++) {
-            seg_start[sg] = a, ch_start[sg] = c, fi_start[sg] = f, bi_start[sg] = bi;
-            const int n = tot[sg], nc = (n + FT_CHUNK - 1) / FT_CHUNK;
-            const int nf = (n + fwd_item - 1) / fwd_item, nb = (nc + g_ch - 1) / g_ch;
-            // equal shares instead of full items + a remainder: (n / nf) rounded up to whole passes; nf never grows
-            fi_per[sg] = nf ? ((n + nf - 1) / nf + 127) / 128 * 128 : fwd_item;
-            bi_per[sg] = nb ? (nc + nb - 1) / nb : g_ch;
-            a += n, c += nc, f += nf ? (n + fi_per[sg] - 1) / fi_per[sg] : 0, bi += nb ? (nc + bi_per[sg] - 1) / bi_per[sg] : 0;
-        }
-        seg_start[nseg] = a, ch_start[nseg] = c, fi_start[nseg] = f, bi_start[nseg] = bi;
-        counts[0] = f, counts[1] = bi, counts[2] = c, counts[3] = 0;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nblk * nseg; i += blockDim.x) blk_cnt[i] = gl[i] + seg_start[i % nseg];
-    for (int i = threadIdx.x; i <= nseg; i += blockDim.x) seg_items[i] = bi_start[i];
-    auto seg_of_slot = [&](const int *start, int i) {
-        int sg = 0;
-        while (sg + 1 < nseg && start[sg + 1] <= i) sg++;
-        return sg;
-    };
-    for (int i = threadIdx.x; i < ch_start[nseg]; i += blockDim.x) {
-        const int sg = seg_of_slot(ch_start, i), j = i - ch_start[sg];
-        chunks[i] = make_int4(sg, seg_start[sg] + j * FT_CHUNK, min(FT_CHUNK, tot[sg] - j * FT_CHUNK), 0);
-    }
-    for (int i = threadIdx.x; i < fi_start[nseg]; i += blockDim.x) {
-        const int sg = seg_of_slot(fi_start, i), j = i - fi_start[sg];
-        fitems[i] = make_int4(sg, seg_start[sg] + j * fi_per[sg], min(fi_per[sg], tot[sg] - j * fi_per[sg]), 0);
-    }
-    for (int i = threadIdx.x; i < bi_start[nseg]; i += blockDim.x) {
-        const int sg = seg_of_slot(bi_start, i), j = i - bi_start[sg];
-        const int nc = ch_start[sg + 1] - ch_start[sg];
-        bitems[i] = make_int4(sg, ch_start[sg] + j * bi_per[sg], min(bi_per[sg], nc - j * bi_per[sg]), 0);
-    }
-}
-
-// pass 3: stable placement (ascending entry id inside a segment)
+// pass 2: stable placement (ascending entry id inside a segment). Every block sums the per-block histograms for
+// itself -- totals and the counts of the blocks before it, nblk * nseg integers that sit in L2 -- instead of waiting
+// for a one-workgroup scan kernel in between (that kernel cost 20-35 us of pure latency on the step's critical
+// path); block 0 also writes the chunk / item tables.
 __global__ __launch_bounds__(GRP_BLOCK) void ft_group_place(const uint8_t *__restrict__ seg_of,
-                                                            const int *__restrict__ blk_base, int nseg, int E,
-                                                            int *__restrict__ elist) {
+                                                            const int *__restrict__ blk_cnt, int nblk, int nseg, int E,
+                                                            int fwd_item, int g_ch, int *__restrict__ elist,
+                                                            int4 *__restrict__ chunks, int4 *__restrict__ fitems,
+                                                            int4 *__restrict__ bitems, int *__restrict__ seg_items,
+                                                            int *__restrict__ counts) {
     __shared__ int wcnt[GRP_BLOCK / 64][256];
+    __shared__ int tot[256], before[256], seg_start[257];
+    __shared__ int ch_start[257], fi_start[257], bi_start[257], fi_per[256], bi_per[256];  // block 0 only
+    for (int i = threadIdx.x; i < nseg; i += GRP_BLOCK) tot[i] = 0, before[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nblk * nseg; i += GRP_BLOCK) {  // integer sums: order does not matter
+        const int v = blk_cnt[i];
+        if (v) {
+            const int blk = i / nseg, sg2 = i - blk * nseg;
+            atomicAdd(&tot[sg2], v);
+            if (blk < (int)blockIdx.x) atomicAdd(&before[sg2], v);
+        }
+    }
     const int e = blockIdx.x * GRP_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sg = e < E ? (int)seg_of[e] : -1;
@@ -264,10 +216,57 @@ __global__ __launch_bounds__(GRP_BLOCK) void ft_group_place(const uint8_t *__res
         if (lane == 0) wcnt[wave][s2] = __popcll(m);
     }
     __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0;
+        for (int s2 = 0; s2 < nseg; s2++) seg_start[s2] = a, a += tot[s2];
+        seg_start[nseg] = a;
+    }
+    __syncthreads();
     if (e < E) {
-        int pos = blk_base[(size_t)blockIdx.x * nseg + sg] + rank;
+        int pos = seg_start[sg] + before[sg] + rank;
         for (int w2 = 0; w2 < wave; w2++) pos += wcnt[w2][sg];
         elist[pos] = e;
+    }
+    if (blockIdx.x != 0) return;
+    for (int s2 = threadIdx.x; s2 < nseg; s2 += GRP_BLOCK) {  // (the divisions in parallel, one segment per thread)
+        const int n = tot[s2], nc = (n + FT_CHUNK - 1) / FT_CHUNK;
+        const int nf = (n + fwd_item - 1) / fwd_item, nb = (nc + g_ch - 1) / g_ch;
+        // equal shares instead of full items + a remainder: (n / nf) rounded up to whole passes; nf never grows
+        fi_per[s2] = nf ? ((n + nf - 1) / nf + 127) / 128 * 128 : fwd_item;
+        bi_per[s2] = nb ? (nc + nb - 1) / nb : g_ch;
+        ch_start[s2] = nc, fi_start[s2] = nf ? (n + fi_per[s2] - 1) / fi_per[s2] : 0;
+        bi_start[s2] = nb ? (nc + bi_per[s2] - 1) / bi_per[s2] : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // counts -> exclusive prefixes
+        int c = 0, f = 0, bi = 0;
+        for (int s2 = 0; s2 < nseg; s2++) {
+            const int nc = ch_start[s2], nf = fi_start[s2], nb = bi_start[s2];
+            ch_start[s2] = c, fi_start[s2] = f, bi_start[s2] = bi;
+            c += nc, f += nf, bi += nb;
+        }
+        ch_start[nseg] = c, fi_start[nseg] = f, bi_start[nseg] = bi;
+        counts[0] = f, counts[1] = bi, counts[2] = c, counts[3] = 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= nseg; i += GRP_BLOCK) seg_items[i] = bi_start[i];
+    auto seg_of_slot = [&](const int *start, int i) {
+        int s2 = 0;
+        while (s2 + 1 < nseg && start[s2 + 1] <= i) s2++;
+        return s2;
+    };
+    for (int i = threadIdx.x; i < ch_start[nseg]; i += GRP_BLOCK) {
+        const int s2 = seg_of_slot(ch_start, i), j = i - ch_start[s2];
+        chunks[i] = make_int4(s2, seg_start[s2] + j * FT_CHUNK, min(FT_CHUNK, tot[s2] - j * FT_CHUNK), 0);
+    }
+    for (int i = threadIdx.x; i < fi_start[nseg]; i += GRP_BLOCK) {
+        const int s2 = seg_of_slot(fi_start, i), j = i - fi_start[s2];
+        fitems[i] = make_int4(s2, seg_start[s2] + j * fi_per[s2], min(fi_per[s2], tot[s2] - j * fi_per[s2]), 0);
+    }
+    for (int i = threadIdx.x; i < bi_start[nseg]; i += GRP_BLOCK) {
+        const int s2 = seg_of_slot(bi_start, i), j = i - bi_start[s2];
+        const int nc = ch_start[s2 + 1] - ch_start[s2];
+        bitems[i] = make_int4(s2, ch_start[s2] + j * bi_per[s2], min(bi_per[s2], nc - j * bi_per[s2]), 0);
     }
 }
 
@@ -2377,15 +2376,10 @@ int bt_internal_ft_build_groups(void *stream, const bt_ft_desc *d, const int32_t
     BT_LAUNCH(BTK_FT_INDEX, s, ft_group_count, dim3(p.grp_blocks), dim3(GRP_BLOCK), 0, i0, i1, d->batch, d->nnz, d->cols,
               p.tc, p.nseg, E, seg_of, blk);
     BT_LAUNCH_CHECK();
-    const size_t lds = (size_t)p.grp_blocks * p.nseg * sizeof(int);
-    if (int rc = set_lds(ft_group_scan, lds)) return rc;
-    BT_LAUNCH(BTK_FT_INDEX, s, ft_group_scan, dim3(1), dim3(256), lds, blk, p.grp_blocks, p.nseg, p.fwd_item, p.g_ch,
-              reinterpret_cast<int4 *>(ws + p.off_chunks), reinterpret_cast<int4 *>(ws + p.off_fitems),
-              reinterpret_cast<int4 *>(ws + p.off_bitems), reinterpret_cast<int *>(ws + p.off_segitems),
-              reinterpret_cast<int *>(ws + p.off_counts));
-    BT_LAUNCH_CHECK();
-    BT_LAUNCH(BTK_FT_INDEX, s, ft_group_place, dim3(p.grp_blocks), dim3(GRP_BLOCK), 0, seg_of, blk, p.nseg, E,
-              reinterpret_cast<int *>(ws + p.off_elist));
+    BT_LAUNCH(BTK_FT_INDEX, s, ft_group_place, dim3(p.grp_blocks), dim3(GRP_BLOCK), 0, seg_of, blk, p.grp_blocks, p.nseg, E,
+              p.fwd_item, p.g_ch, reinterpret_cast<int *>(ws + p.off_elist), reinterpret_cast<int4 *>(ws + p.off_chunks),
+              reinterpret_cast<int4 *>(ws + p.off_fitems), reinterpret_cast<int4 *>(ws + p.off_bitems),
+              reinterpret_cast<int *>(ws + p.off_segitems), reinterpret_cast<int *>(ws + p.off_counts));
     BT_LAUNCH_CHECK();
     return BT_OK;
 }
