@@ -243,9 +243,13 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
     consumed = [handle(L.bt_event_create) for _ in range(SETS)]
     copy = handle(L.bt_stream_create)
     X = os.environ.get("BENCH_X", "").split(",")  # "devwait": the experiment described in step()
-    stream = torch.cuda.current_stream().cuda_stream
+    # the step's own (non-blocking) compute stream: nothing of it rides on the legacy NULL stream, whose implicit
+    # joins with other streams are no business of an RCCL collective
+    stream_h = handle(L.bt_stream_create)
+    stream = stream_h.value
     adj = torch.tensor([parallel.adj_factor(global_batch)], device="cuda")
     lr = torch.tensor([1e-3], device="cuda")
+    torch.cuda.synchronize()  # parameters, adj, lr: written on torch's stream
     multi_layer = net_name != "cfg2" and not args.no_hints
     nbytes = words * 4
 
@@ -298,6 +302,7 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
         for e in uploaded + consumed:
             L.bt_event_destroy(e)
         L.bt_stream_destroy(copy)
+        L.bt_stream_destroy(stream_h)
         for hp in host_packs:
             L.bt_host_free_pinned(hp)
         net.close()
@@ -319,7 +324,7 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
     dom = max(cand, key=lambda k: cand[k][1]) if cand else None
     SAMPLE = 8
     if comm is not None:
-        comm.barrier()
+        comm.barrier(stream)
     if profile and dom:
         lib.profile_start(steps * 2 + 64, only=[dom], every=SAMPLE)
     torch.cuda.synchronize()
@@ -328,7 +333,7 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
         step()
     torch.cuda.synchronize()
     if comm is not None:
-        comm.barrier()
+        comm.barrier(stream)
     elapsed = time.perf_counter() - t0
     kern = lib.profile_stop() if (profile and dom) else {}
     res = {"elapsed": elapsed, "loss": net.loss.item() / global_batch, "nbar": float(nbar), "warm": warm, "dom": dom,
@@ -337,10 +342,10 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
     if comm is not None and comm.world > 1:  # the exchange alone, same buffers, back to back
         reps = 50
         torch.cuda.synchronize()
-        comm.barrier()
+        comm.barrier(stream)
         t1 = time.perf_counter()
         for _ in range(reps):
-            comm.all_reduce(net.step_buffer)
+            comm.all_reduce(net.step_buffer, stream)
         torch.cuda.synchronize()
         res["allreduce_us"] = (time.perf_counter() - t1) / reps * 1e6
         res["allreduce_bytes"] = net.step_buffer.numel() * 4

@@ -139,13 +139,18 @@ class Comm:
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
         lib.check(lib.load().bt_allreduce_sum_f32(self.h, s, tensor.data_ptr(), tensor.numel()))
 
-    def barrier(self):
-        """every rank has reached this point (a 1-float all-reduce, waited for)"""
+    def barrier(self, stream=None):
+        """every rank has reached this point (a 1-float all-reduce on `stream`, waited for)"""
         import torch
+        from . import lib
         if self._token is None:
             self._token = torch.zeros(1, device="cuda")
-        self.all_reduce(self._token)
-        torch.cuda.current_stream().synchronize()
+            torch.cuda.synchronize()
+        self.all_reduce(self._token, stream)
+        if stream is None:
+            torch.cuda.current_stream().synchronize()
+        else:
+            lib.check(lib.load().bt_stream_sync(stream))
 
     def close(self):
         if self.h:
