@@ -842,6 +842,9 @@ __global__ void colsum_final(const float *__restrict__ partial, int nblk, int C,
 constexpr int LDS_RT = 32;
 constexpr int LDS_THREADS = 1024;
 
+__device__ __forceinline__ float row_ror8(float v) {  // the value of lane ^ 8 (rotation by 8 inside each 16-lane row)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, true));
+}
 template <int N>
 __device__ __forceinline__ int row_share(int v) {  // broadcast lane N of each 16-lane row (DPP, no LDS traffic)
     return __builtin_amdgcn_update_dpp(v, v, 0x150 + N, 0xF, 0xF, true);
@@ -1580,9 +1583,9 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
     int r_eid[NPASS], r_ne = 0;
     uint32_t p_r0 = 0, p_r1 = 0, p_nfix = 0;  // the prefetched chunk's row range of this wave, its cut features
     uint2 p_fix = make_uint2(0u, 0u);
-    oct_f32x4 hd[4];                          // HDW: dW1 accumulators [bucket rows 4 * (lane / 16) ..][column lane % 16]
+    oct_f32x4 hd[2];                          // HDW: dW1 accumulators [bucket rows 4 * (lane / 16) ..][column slot lane % 16]
 #pragma unroll
-    for (int i = 0; i < 4; i++) hd[i] = oct_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = 0; i < 2; i++) hd[i] = oct_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     const uint32_t t_col = PAIR ? rt * 16 + (s8 & 3) * 4 : rt * LDS_RT + s8 * 4;
     auto load_eids = [&](int c) {
         if constexpr (GRP) {
@@ -1691,22 +1694,24 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
             const int el = el0 + pass * 128;
             if constexpr (HDW) {
                 // (whole wave: MFMA runs on all lanes; entries past the chunk's end count with gz = 0)
+                // A 16-lane row holds the entries 2k (lanes 0-7) and 2k + 1 (lanes 8-15), 8 lanes x float4 each. The
+                // B operand wants one entry per row (k = lane / 16), so the two halves trade half their float4
+                // (one DPP rotation by 8 lanes per value): afterwards the row holds entry 2k as 16 x float2 in
+                // (e0, e1) and entry 2k + 1 in (o0, o1), column 4 * (n & 7) + 2 * (n >> 3) + component for lane n.
                 const float gzv = el < n_e ? r_go[pass].x : 0.0f;
                 const int bk = __float_as_int(r_go[pass].y);
                 const float4 o = r_a[pass];
-                const bool odd = (threadIdx.x >> 3) & 1;
-                const float4 pe = odd ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(gzv * o.x, gzv * o.y, gzv * o.z, gzv * o.w);
-                const float4 po = odd ? make_float4(gzv * o.x, gzv * o.y, gzv * o.z, gzv * o.w) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                const float4 pv = make_float4(gzv * o.x, gzv * o.y, gzv * o.z, gzv * o.w);
+                const bool hi = (threadIdx.x >> 3) & 1;
+                const float x0 = row_ror8(hi ? pv.x : pv.z), x1 = row_ror8(hi ? pv.y : pv.w);  // from lane ^ 8
+                const float e0 = hi ? x0 : pv.x, e1 = hi ? x1 : pv.y;
+                const float o0 = hi ? pv.z : x0, o1 = hi ? pv.w : x1;
                 const int m = threadIdx.x & 15;
                 const float a_e = row_share<0>(bk) == m ? 1.0f : 0.0f, a_o = row_share<8>(bk) == m ? 1.0f : 0.0f;
-                hd[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_e, pe.x, hd[0], 0, 0, 0);
-                hd[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_e, pe.y, hd[1], 0, 0, 0);
-                hd[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_e, pe.z, hd[2], 0, 0, 0);
-                hd[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_e, pe.w, hd[3], 0, 0, 0);
-                hd[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, po.x, hd[0], 0, 0, 0);
-                hd[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, po.y, hd[1], 0, 0, 0);
-                hd[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, po.z, hd[2], 0, 0, 0);
-                hd[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, po.w, hd[3], 0, 0, 0);
+                hd[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_e, e0, hd[0], 0, 0, 0);
+                hd[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_e, e1, hd[1], 0, 0, 0);
+                hd[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, o0, hd[0], 0, 0, 0);
+                hd[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, o1, hd[1], 0, 0, 0);
             }
             if (el < n_e) {
                 float4 go = r_go[pass];
@@ -1804,16 +1809,16 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
         partial_b[(size_t)cg * d.rows + tile_row(PAIR, rt, half_rows, threadIdx.x)] = s;
     }
     if constexpr (HDW) {
-        // the waves' dW1 accumulators -> one partial per (bucket, column) of this tile, waves and halves in order.
-        // The dW tile has been written out (barriers above), so its LDS holds the 16 x w1_rows x 64 floats.
+        // the waves' dW1 accumulators -> one partial per (bucket, column) of this tile, the waves in order.
+        // The dW tile has been written out (barriers above), so its LDS holds the 16 x w1_rows x 32 floats.
         float *tmp = acc;
         const int lane = threadIdx.x & 63, qd = lane >> 4, j = lane & 15;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int m = 4 * qd + r;
             if (m < fs.w1_rows) {
-                float *t2 = tmp + (((size_t)wv * fs.w1_rows + m) * 2 + (j >> 3)) * 32 + 4 * (j & 7);
-                t2[0] = hd[0][r], t2[1] = hd[1][r], t2[2] = hd[2][r], t2[3] = hd[3][r];
+                float *t2 = tmp + ((size_t)wv * fs.w1_rows + m) * 32 + 4 * (j & 7) + 2 * (j >> 3);
+                t2[0] = hd[0][r], t2[1] = hd[1][r];
             }
         }
         __syncthreads();
@@ -1821,10 +1826,7 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
         for (int q = threadIdx.x; q < fs.w1_rows * 32; q += LDS_THREADS) {
             const int m = q >> 5, col = q & 31;
             float s = 0.0f;
-            for (int w2 = 0; w2 < OCT_WAVES; w2++) {
-                s += tmp[(((size_t)w2 * fs.w1_rows + m) * 2 + 0) * 32 + col];
-                s += tmp[(((size_t)w2 * fs.w1_rows + m) * 2 + 1) * 32 + col];
-            }
+            for (int w2 = 0; w2 < OCT_WAVES; w2++) s += tmp[((size_t)w2 * fs.w1_rows + m) * 32 + col];
             hg.pw1[(size_t)cg * hg.pw1_stride + (size_t)(kk * out_w + rt * 32 + col) * fs.w1_rows + m] = s;
         }
     }

@@ -5,7 +5,7 @@ mkdir -p gpurun_out/exp
 for name in real "$@"; do
   for occ in full fixture; do
     if [ $name = real ]; then unset BT_LIB_PATH; else export BT_LIB_PATH=tools/libbullet_amd_$name.so; fi
-    timeout -k 10 300 python bench.py --no-cpu-baseline --occupancy $occ > gpurun_out/exp/bench_${name}_$occ.txt 2>&1 || { tail -n 5 gpurun_out/exp/bench_${name}_$occ.txt; exit 1; }
+    timeout -k 10 300 python bench.py --no-cpu-baseline --no-subrecords --occupancy $occ > gpurun_out/exp/bench_${name}_$occ.txt 2>&1 || { tail -n 5 gpurun_out/exp/bench_${name}_$occ.txt; exit 1; }
     tail -n 1 gpurun_out/exp/bench_${name}_$occ.txt | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read())
