@@ -310,6 +310,17 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
     # Per-kernel HIP-event timing costs ~20 % of a 0.25 ms step when every kernel is timed, so the full per-kernel
     # table is taken over the warm-up steps and the timed region times only the dominant kernel -- and only every
     # SAMPLE-th launch of it. The average over the samples agrees with the rocprofv3 kernel trace (profiles/README.md).
+    # Clocks: the GPU needs tens of milliseconds of load to leave its idle power state, and a driver may ask for as
+    # few as W = 5 warm-up steps (1 ms). Forward-only passes (bt_net_forward: no parameter, gradient or optimiser
+    # state changes hands) keep it busy for --spinup-ms first; the W warm-up steps and the K timed steps follow.
+    if args.spinup_ms > 0:
+        upl = uploaded[0]
+        L.bt_stream_wait_event(stream, upl)
+        t_spin = time.perf_counter()
+        while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+            for _ in range(16):
+                lib.check(L.bt_net_forward(net.h, stream, C.byref(dev_batches[0]), None, None))
+            lib.check(L.bt_stream_sync(stream))
     profile = not args.no_profile
     if profile and warmup > 0:
         lib.profile_start(warmup * 24 + 64)
@@ -388,6 +399,9 @@ def main():
                     help="what crosses PCIe for the next batch inside the timed loop: the 32-byte records (mapped on the "
                          "device by bt_map_batch_device behind the copy; 32 B/position, the training loop's device_mapper "
                          "path), the five mapped tensors (268 B/position), or nothing (an experiment, not the contract)")
+    ap.add_argument("--spinup-ms", type=float, default=150.0,
+                    help="milliseconds of forward-only passes before the warm-up steps (GPU clock ramp; no training state "
+                         "is touched)")
     ap.add_argument("--no-hints", action="store_true",
                     help="multi-layer nets: do not announce the next batch (bt_net_hint_next_batch), so its index "
                          "structures are built on the step's own critical path")
@@ -452,7 +466,7 @@ def main():
             "config": {"workload": main_res["workload"], "batch_per_gpu": B, "global_batch": args.batch,
                        "occupancy": args.occupancy, "mean_active_features": rec["mean_active_features"],
                        "parallelism": f"dp{world}",
-                       "upload": args.upload,
+                       "upload": args.upload, "spinup_ms": args.spinup_ms,
                        "step": "pinned-host -> HBM upload of the next batch (copy stream"
                                + (", 32-byte records + bt_map_batch_device" if args.upload == "records" else "")
                                + ") || fwd + bwd"

@@ -13,12 +13,15 @@ import bench  # noqa: E402
 from bullet_amd import lib  # noqa: E402
 
 STEPS, WARM = 20, 2
-sys.argv = [sys.argv[0], "--steps", str(STEPS), "--warmup", str(WARM), "--no-cpu-baseline", "--no-profile"] + sys.argv[1:]
+sys.argv = [sys.argv[0], "--steps", str(STEPS), "--warmup", str(WARM), "--no-cpu-baseline", "--no-profile",
+            "--no-subrecords"] + sys.argv[1:]
 L = lib.load()
 buf = (C.c_ulonglong * 128)()
 bench.main()
 assert L.bt_oct_debug_read(buf) == 0
-names = ["prologue", "work", "loads", "waitX", "fixup", "waitY", "end", "-"]
+# phases of ft_bwd_oct_body (OT(i)): before the loop | loop tail -> top | wait at the first chunk barrier | first stream
+# rows + fix-up + staging | wait at the second barrier | issuing the next chunk's loads | the reduction | after the loop
+names = ["prologue", "looptail", "waitA", "stage", "waitB", "prefetch", "reduce", "end"]
 print("cycles per launch; wave " + " ".join(f"{n:>9s}" for n in names))
 for w in range(16):
     print(f"{w:4d} " + " ".join(f"{buf[w * 8 + i] / (STEPS + WARM):9.0f}" for i in range(8)))
