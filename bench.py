@@ -333,7 +333,7 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
     cand = {k: v for k, v in warm.items() if k.startswith("ft_") and k != "ft_index_kernel"} or \
            {k: v for k, v in warm.items() if k != "ft_index_kernel"}
     dom = max(cand, key=lambda k: cand[k][1]) if cand else None
-    SAMPLE = 8
+    SAMPLE = 8 if steps >= 64 else 4  # (a short run still gets a handful of timed launches)
     if comm is not None:
         comm.barrier(stream)
     if profile and dom:
