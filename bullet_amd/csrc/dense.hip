@@ -287,6 +287,25 @@ __global__ __launch_bounds__(256) void weight_clip_kernel(float *__restrict__ w,
     if (i < n) w[i] = fmaxf(fminf(w[i], hi), lo);  // clip.rs:25-28: min with max first, then max with min
 }
 
+// ModelNode::clip_pass_through_grad (compiler/src/model/operations/pointwise.rs:272-300): x.max(min).min(max); its
+// gradient is the incoming one, untouched (tensor/operation/autograd/passthrough.rs:31-33)
+__global__ __launch_bounds__(256) void clip_pass_through_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                                size_t n, float lo, float hi) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = fminf(fmaxf(x[i], lo), hi);
+}
+
+// ModelNode::faux_quantise (pointwise.rs:196-221): (value * x).round() or .trunc(), times the reciprocal of value;
+// roundf / truncf as the reference's generated code calls them (gpu/src/pointwise/write.rs:196-197)
+__global__ __launch_bounds__(256) void faux_quantise_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n,
+                                                            float value, int round) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float denom = 1.0f / value, scaled = value * x[i];
+        y[i] = (round ? roundf(scaled) : truncf(scaled)) * denom;
+    }
+}
+
 __global__ __launch_bounds__(256) void weight_decay_kernel(float *__restrict__ w, size_t n, float decay,
                                                            const float *__restrict__ lr) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1826,6 +1845,23 @@ int bt_weight_clip(void *stream, float *w, size_t n, float min_w, float max_w) {
     BT_REQUIRE(w && n > 0, "bt_weight_clip: null/empty buffer");
     BT_LAUNCH(BTK_ADAMW, bt_stream(stream), weight_clip_kernel, dim3(bt_div_up((long long)n, 256)), dim3(256), 0, w, n,
               min_w, max_w);
+    BT_LAUNCH_CHECK();
+    return BT_OK;
+}
+
+int bt_clip_pass_through(void *stream, const float *x, float *y, size_t n, float min_v, float max_v) {
+    BT_REQUIRE(x && y && n > 0, "bt_clip_pass_through: null/empty buffer");
+    BT_LAUNCH(BTK_ADAMW, bt_stream(stream), clip_pass_through_kernel, dim3(bt_div_up((long long)n, 256)), dim3(256), 0, x,
+              y, n, min_v, max_v);
+    BT_LAUNCH_CHECK();
+    return BT_OK;
+}
+
+int bt_faux_quantise(void *stream, const float *x, float *y, size_t n, float value, int round) {
+    BT_REQUIRE(x && y && n > 0, "bt_faux_quantise: null/empty buffer");
+    BT_REQUIRE(value != 0.0f, "bt_faux_quantise: value must not be zero");
+    BT_LAUNCH(BTK_ADAMW, bt_stream(stream), faux_quantise_kernel, dim3(bt_div_up((long long)n, 256)), dim3(256), 0, x, y, n,
+              value, round);
     BT_LAUNCH_CHECK();
     return BT_OK;
 }

@@ -148,6 +148,7 @@ SYMBOLS = [
     "bt_ft_backward_prebuilt", "bt_ft_forward_prebuilt", "bt_ft_segment_violations",
     "bt_dense_forward", "bt_dense_backward_workspace_bytes", "bt_dense_backward", "bt_dense_backward_static",
     "bt_sigmoid_mse", "bt_loss", "bt_adamw", "bt_radam", "bt_lookahead", "bt_weight_clip", "bt_weight_decay",
+    "bt_clip_pass_through", "bt_faux_quantise",
     "bt_net_set_optimiser",
     "bt_net_param_count", "bt_net_num_tensors", "bt_net_tensor_size", "bt_net_tensor_offset", "bt_net_create",
     "bt_net_destroy", "bt_net_params", "bt_net_grads", "bt_net_momentum", "bt_net_velocity", "bt_net_set_adamw",
@@ -226,6 +227,8 @@ def load():
                           C.c_void_p, C.c_void_p]
     L.bt_weight_clip.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float]
     L.bt_weight_decay.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p]
+    L.bt_clip_pass_through.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float]
+    L.bt_faux_quantise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_int]
     L.bt_adamw.argtypes = [C.c_void_p, C.c_int, C.POINTER(AdamwTensor), C.c_void_p, C.c_void_p]
     L.bt_radam.argtypes = [C.c_void_p, C.c_int, C.POINTER(AdamwTensor), C.c_void_p, C.c_void_p, C.c_int, C.c_float]
     L.bt_lookahead.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),

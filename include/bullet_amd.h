@@ -248,6 +248,15 @@ int bt_lookahead(void *stream, int n_tensors, float *const *params, float *const
  * clip: w = max(min(w, max), min); decay: w = w * (1 + -1 * (lr * decay)), lr read from its 1-element device buffer */
 int bt_weight_clip(void *stream, float *w, size_t n, float min_w, float max_w);
 int bt_weight_decay(void *stream, float *w, size_t n, float decay, const float *lr_dev);
+/* ModelNode::clip_pass_through_grad(min, max) (compiler/src/model/builder.rs:365-368, model/operations/pointwise.rs:
+ * 272-300): y = min(max(x, min), max). Its backward hands the incoming gradient on unchanged
+ * (autograd/passthrough.rs:31-33): the caller uses grad_y as grad_x, there is no kernel. y may be x. */
+int bt_clip_pass_through(void *stream, const float *x, float *y, size_t n, float min_v, float max_v);
+/* ModelNode::faux_quantise(value, round) (builder.rs:370-373, pointwise.rs:196-221): y = round_or_trunc(value * x) *
+ * (1 / value), roundf / truncf as in the generated code (gpu/src/pointwise/write.rs:196-197). Forward only, as in the
+ * reference: the graph it lowers to has no gradient (Unary::Round / Truncate: `unimplemented!()`,
+ * tensor/operation/pointwise/unary.rs:160-162), so it cannot sit on a trained path there either. y may be x. */
+int bt_faux_quantise(void *stream, const float *x, float *y, size_t n, float value, int round);
 
 /* ------------------------------------------------------------------------------------------
  * 3. The lowered training step for the ValueTrainerBuilder net family

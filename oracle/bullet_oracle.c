@@ -254,6 +254,25 @@ void orc_weight_clip(float *w, size_t n, float min_w, float max_w) {
     }
 }
 
+/* ModelNode::clip_pass_through_grad: x.max(min).min(max) (compiler/src/model/operations/pointwise.rs:289-298);
+ * backward = the incoming gradient (tensor/operation/autograd/passthrough.rs:31-33) */
+void orc_clip_pass_through(const float *x, float *y, size_t n, float min_v, float max_v) {
+    for (size_t i = 0; i < n; i++) {
+        float low = x[i] > min_v ? x[i] : min_v;
+        y[i] = low < max_v ? low : max_v;
+    }
+}
+
+/* ModelNode::faux_quantise: scalar * input -> Round | Truncate -> * Reciprocal(scalar)
+ * (compiler/src/model/operations/pointwise.rs:212-220; f32::round = half away from zero, unary.rs:51-52) */
+void orc_faux_quantise(const float *x, float *y, size_t n, float value, int round) {
+    const float denom = 1.0f / value;
+    for (size_t i = 0; i < n; i++) {
+        const float scaled = value * x[i];
+        y[i] = (round ? roundf(scaled) : truncf(scaled)) * denom;
+    }
+}
+
 void orc_weight_decay(float *w, size_t n, float decay, float lr) {
     for (size_t i = 0; i < n; i++) w[i] = w[i] * (1.0f + (-1.0f * (lr * decay)));
 }

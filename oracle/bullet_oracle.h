@@ -93,6 +93,8 @@ float orc_loss(int kind, int batch, int width, const float *y, const float *targ
 
 /* WeightClipping / WeightDecay kernels, optimiser/clip.rs:18-31, decay.rs:18-40 */
 void orc_weight_clip(float *w, size_t n, float min_w, float max_w);
+void orc_clip_pass_through(const float *x, float *y, size_t n, float min_v, float max_v);
+void orc_faux_quantise(const float *x, float *y, size_t n, float value, int round);
 void orc_weight_decay(float *w, size_t n, float decay, float lr);
 
 /* ------------------------------------------------------------------ net */

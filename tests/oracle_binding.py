@@ -122,6 +122,18 @@ def weight_clip(w, lo, hi):
     lib().orc_weight_clip(fp(w), C.c_size_t(w.size), C.c_float(lo), C.c_float(hi))
 
 
+def clip_pass_through(x, lo, hi):
+    y = np.empty_like(x)
+    lib().orc_clip_pass_through(fp(x), fp(y), C.c_size_t(x.size), C.c_float(lo), C.c_float(hi))
+    return y
+
+
+def faux_quantise(x, value, round_):
+    y = np.empty_like(x)
+    lib().orc_faux_quantise(fp(x), fp(y), C.c_size_t(x.size), C.c_float(value), C.c_int(int(round_)))
+    return y
+
+
 def weight_decay(w, decay, lr):
     lib().orc_weight_decay(fp(w), C.c_size_t(w.size), C.c_float(decay), C.c_float(lr))
 

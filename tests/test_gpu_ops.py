@@ -318,6 +318,26 @@ def test_weight_clip_and_decay_vs_oracle():
     assert w.max() == 1.5 and w.min() == np.float32(-1.98)
 
 
+def test_clip_pass_through_and_faux_quantise_vs_oracle():
+    """clip_pass_through_grad / faux_quantise forward kernels (model/operations/pointwise.rs:196-221,272-300): bit-exact
+    with the oracle (single roundings, no contraction possible), in place and out of place"""
+    rng = np.random.default_rng(12)
+    x = (rng.standard_normal(100003) * 1.5).astype(np.float32)
+    x[:4] = [0.5 / 255, -0.5 / 255, 1.5 / 255, 1e9]
+    dx, dy = gu.dev(x), gu.dev(np.zeros_like(x))
+    lib.check(L.bt_clip_pass_through(gu.stream(), dx.data_ptr(), dy.data_ptr(), x.size, -1.98, 1.5))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(dy.cpu().numpy(), ob.clip_pass_through(x, -1.98, 1.5))
+    for value, rnd in ((255.0, True), (255.0, False), (64.0, True), (0.3, False)):
+        lib.check(L.bt_faux_quantise(gu.stream(), dx.data_ptr(), dy.data_ptr(), x.size, value, int(rnd)))
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(dy.cpu().numpy(), ob.faux_quantise(x, value, rnd))
+    lib.check(L.bt_faux_quantise(gu.stream(), dx.data_ptr(), dx.data_ptr(), x.size, 255.0, 1))  # in place
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(dx.cpu().numpy(), ob.faux_quantise(x, 255.0, True))
+    assert L.bt_faux_quantise(gu.stream(), dx.data_ptr(), dy.data_ptr(), x.size, 0.0, 1) != 0
+
+
 def test_adamw_multi_tensor_vs_oracle():
     rng = np.random.default_rng(3)
     sizes = [786432, 1024, 16384, 8, 5, 1023]  # incl. sizes not divisible by 4 (scalar tail, adam.rs:139-158)

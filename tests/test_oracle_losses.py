@@ -65,6 +65,21 @@ def test_weight_clip_and_decay():
     assert w.tolist() == [f, np.float32(-2.0) * f]
 
 
+def test_clip_pass_through_and_faux_quantise():
+    """the two leftover pointwise model ops (builder.rs:365-373). The reference holds no vectors for them (parity
+    unpinned): the oracle is checked against the formulas written out in numpy float32."""
+    x = np.array([-3.0, -1.98, -0.26, 0.0, 0.2549, 0.25, 1.98, 2.5], np.float32)
+    assert ob.clip_pass_through(x, -1.98, 1.98).tolist() == np.clip(x, np.float32(-1.98), np.float32(1.98)).tolist()
+    q = np.float32(255.0)
+    scaled = q * x
+    half_away = np.sign(scaled) * np.floor(np.abs(scaled) + np.float32(0.5))  # f32::round: ties away from zero
+    assert ob.faux_quantise(x, 255.0, True).tolist() == (half_away * (np.float32(1.0) / q)).astype(np.float32).tolist()
+    assert ob.faux_quantise(x, 255.0, False).tolist() == (np.trunc(scaled) * (np.float32(1.0) / q)).astype(np.float32).tolist()
+    tie = np.array([0.5, -0.5, 1.5, 2.5], np.float32)  # value 1: round() must not be round-half-to-even
+    assert ob.faux_quantise(tie, 1.0, True).tolist() == [1.0, -1.0, 2.0, 3.0]
+    assert ob.faux_quantise(tie, 1.0, False).tolist() == [0.0, -0.0, 1.0, 2.0]
+
+
 def test_wdl_net_oracle_gradient_matches_finite_differences():
     """3-output net with softmax-CE on one-hot targets: dL/d(bias of the head) by central differences"""
     rng = np.random.default_rng(0)
