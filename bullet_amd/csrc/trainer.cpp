@@ -259,8 +259,8 @@ extern "C" int bt_reader_open(const char *const *paths, int n_paths, uint64_t st
 }
 
 extern "C" int bt_reader_next(bt_reader *r, void *dst, int count) {
-    BT_REQUIRE(r && dst && count >= 0, "bt_reader_next: bad arguments");
-    uint8_t *p = static_cast<uint8_t *>(dst);
+    BT_REQUIRE(r && count >= 0, "bt_reader_next: bad arguments");
+    uint8_t *p = static_cast<uint8_t *>(dst);  // NULL: the records are skipped (a data-parallel rank's foreign shards)
     size_t need = (size_t)count;
     if (r->refill) {  // one shuffle buffer after the other (viribinpack.rs:143-148)
         while (need > 0) {
@@ -273,16 +273,16 @@ extern "C" int bt_reader_next(bt_reader *r, void *dst, int count) {
                 }
             }
             const size_t take = std::min(need, r->mem.size() / 32 - r->mem_pos);
-            std::memcpy(p, r->mem.data() + r->mem_pos * 32, take * 32);
-            p += take * 32, need -= take, r->mem_pos += take;
+            if (p) std::memcpy(p, r->mem.data() + r->mem_pos * 32, take * 32), p += take * 32;
+            need -= take, r->mem_pos += take;
         }
         return BT_OK;
     }
     if (!r->mem.empty()) {  // in-memory text positions: the whole set again and again (text.rs:30-34)
         while (need > 0) {
             const size_t take = std::min(need, r->mem.size() / 32 - r->mem_pos);
-            std::memcpy(p, r->mem.data() + r->mem_pos * 32, take * 32);
-            p += take * 32, need -= take;
+            if (p) std::memcpy(p, r->mem.data() + r->mem_pos * 32, take * 32), p += take * 32;
+            need -= take;
             r->mem_pos = (r->mem_pos + take) % (r->mem.size() / 32);
         }
         return BT_OK;
@@ -300,8 +300,17 @@ extern "C" int bt_reader_next(bt_reader *r, void *dst, int count) {
                 r->to_skip = 0;
             }
         }
-        const size_t got = std::fread(p, 32, need, r->fp);
-        p += got * 32;
+        size_t got;
+        if (p) {
+            got = std::fread(p, 32, need, r->fp);
+            p += got * 32;
+        } else {  // skip: whole records up to the end of this file
+            const long cur = std::ftell(r->fp);
+            std::fseek(r->fp, 0, SEEK_END);
+            const long end = std::ftell(r->fp);
+            got = std::min(need, (size_t)((end - cur) / 32));
+            std::fseek(r->fp, cur + (long)(got * 32), SEEK_SET);
+        }
         need -= got;
         if (need > 0) {  // end of this file: next file, wrapping forever (fixed_size.rs:73-106)
             std::fclose(r->fp);
@@ -493,7 +502,7 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
     float lr_slot[LOSS_RING] = {0.0f};
     bool lr_slot_set[LOSS_RING] = {false};
     float *loss_host = nullptr, *lr_host = nullptr, *loss_dev = nullptr, *lr_dev = nullptr, *adj_dev = nullptr;
-    std::vector<uint8_t> records((size_t)BG * 32);
+    std::vector<uint8_t> records((size_t)B * 32);  // (host mapper: this rank's shard of a batch)
     int rc = BT_OK;
     Loader L;
     std::thread loader_thread;
@@ -609,20 +618,23 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
             HostSlot &s = slots[slot];
             s.blend = o.blend;
             int lrc;
+            // data parallel: every rank walks the same record stream and keeps its shard [lo, lo + B) of each global
+            // batch; the other ranks' records are skipped (a seek for plain files), not read
+            auto read_shard = [&](uint8_t *dst) -> int {
+                if (!dp) return bt_reader_next(reader, dst, B);
+                if (int r2 = bt_reader_next(reader, nullptr, lo)) return r2;
+                if (int r2 = bt_reader_next(reader, dst, B)) return r2;
+                return bt_reader_next(reader, nullptr, BG - lo - B);
+            };
             if (dev_map) {  // raw records straight into the pinned slot; the device maps them after the upload
-                if (dp) {  // every rank walks the same record stream and keeps its shard
-                    lrc = bt_reader_next(reader, records.data(), BG);
-                    if (!lrc) std::memcpy(s.records, records.data() + (size_t)lo * 32, (size_t)B * 32);
-                } else {
-                    lrc = bt_reader_next(reader, s.records, B);
-                }
+                lrc = read_shard(s.records);
                 if (!lrc && !o.wdl_output && !(o.blend >= 0.0f && o.blend <= 1.0f)) {
                     bt_set_error("WDL proportion must be in [0, 1]");  // value.rs:114
                     lrc = BT_ERR_INVALID;
                 }
             } else {
-                lrc = bt_reader_next(reader, records.data(), BG);
-                if (!lrc) lrc = bt_map_batch(input, &o, records.data() + (size_t)lo * 32, B, s.stm, s.nstm, s.buckets, s.targets, s.weights);
+                lrc = read_shard(records.data());
+                if (!lrc) lrc = bt_map_batch(input, &o, records.data(), B, s.stm, s.nstm, s.buckets, s.targets, s.weights);
             }
             s.superbatch = sb, s.batch = batch;
             {

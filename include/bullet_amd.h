@@ -468,6 +468,8 @@ typedef struct bt_reader bt_reader;
  * `<fen> | <score> | <result>` position per line, all parsed up front with bt_chessboard_from_str and then served
  * round and round; start_position is ignored there, as in the reference. */
 int bt_reader_open(const char *const *paths, int n_paths, uint64_t start_position, bt_reader **reader);
+/* dst_records == NULL skips `count` records (a seek for plain files): how a data-parallel rank passes over the other
+ * ranks' shards of a global batch */
 int bt_reader_next(bt_reader *reader, void *dst_records, int count);
 /* ViriBinpackLoader (value/loader/viribinpack.rs:37-152): games in viriformat are replayed into bulletformat positions
  * on `threads` workers and pass through a shuffle buffer of buffer_size_mb * 2^20 / 32 / 2 positions (Fisher-Yates

@@ -84,6 +84,10 @@ def test_reader_loops_files_and_honours_start(tmp_path):
             exp = stream[(pos + np.arange(count)) % 1700]
             assert np.array_equal(out, exp), (start, count)
             pos = (pos + count) % 1700
+            # a NULL destination skips records (across file ends too): how a data-parallel rank passes foreign shards
+            skip = (count * 7) % 2500
+            lib.check(L.bt_reader_next(h, None, skip))
+            pos = (pos + skip) % 1700
         L.bt_reader_close(h)
     h = C.c_void_p()
     bad = (C.c_char_p * 1)(b"/nonexistent/file.bf")
@@ -167,6 +171,9 @@ def test_text_reader_serves_the_lines_round_and_round(tmp_path):
     assert np.array_equal(out, rec[np.arange(130) % 53])
     lib.check(L.bt_reader_next(h, out.ctypes.data, 10))
     assert np.array_equal(out[:10], rec[(130 + np.arange(10)) % 53])
+    lib.check(L.bt_reader_next(h, None, 60))  # skipped
+    lib.check(L.bt_reader_next(h, out.ctypes.data, 10))
+    assert np.array_equal(out[:10], rec[(200 + np.arange(10)) % 53])
     L.bt_reader_close(h)
     path.write_text("not a position\n")
     assert L.bt_reader_open(paths, 1, 0, C.byref(h)) != 0 and b"line 1" in L.bt_last_error()
