@@ -427,6 +427,7 @@ def main():
         raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     dist = comm = None
+    comm_kind = None
     if world > 1:
         import torch.distributed as dist
         # torch.distributed is the launcher's rendezvous (it carries the RCCL id and the final max-over-ranks); the
@@ -436,10 +437,25 @@ def main():
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            comm = parallel.Comm.rccl(dist)
+            try:
+                comm = parallel.Comm.rccl(dist)
+                comm_kind = "native RCCL communicator (bt_comm_init_rank)"
+            except Exception as e:  # the same collectives through torch.distributed's RCCL, as hooks: slower host path
+                print(f"rank {rank}: native communicator unavailable ({e}); falling back to torch.distributed hooks",
+                      file=sys.stderr)
+                comm = parallel.Comm.from_torch(dist)
+                comm_kind = "torch.distributed (RCCL) through bt_comm_from_hooks"
+            # every rank must have taken the same path
+            flag = torch.tensor([0 if comm_kind.startswith("native") else 1], device="cuda")
+            dist.all_reduce(flag)
+            if 0 < flag.item() < world:
+                comm.close()
+                comm = parallel.Comm.from_torch(dist)
+                comm_kind = "torch.distributed (RCCL) through bt_comm_from_hooks"
         else:
             dist.init_process_group(backend)
             comm = parallel.Comm.from_torch(dist)
+            comm_kind = f"torch.distributed ({backend}) through bt_comm_from_hooks"
     lib.load()
 
     def tmax(x):
@@ -465,7 +481,7 @@ def main():
             "data": "synthetic" if not args.records else "file:" + os.path.basename(args.records),
             "config": {"workload": main_res["workload"], "batch_per_gpu": B, "global_batch": args.batch,
                        "occupancy": args.occupancy, "mean_active_features": rec["mean_active_features"],
-                       "parallelism": f"dp{world}",
+                       "parallelism": f"dp{world}", "collective": comm_kind,
                        "upload": args.upload, "spinup_ms": args.spinup_ms,
                        "step": "pinned-host -> HBM upload of the next batch (copy stream"
                                + (", 32-byte records + bt_map_batch_device" if args.upload == "records" else "")
