@@ -466,8 +466,10 @@ __device__ __forceinline__ int oct_wave_of(int o) {  // serpentine deal of octet
     return (r & 1) ? 15 - i : i;
 }
 
+// (min. 6 waves per SIMD = at most 80 VGPRs: a workgroup of this kernel then fits beside a resident FT-forward
+// workgroup -- 4 x 88 registers per SIMD lane -- and the index build hides under the forward pass)
 template <bool GRP>
-__global__ __launch_bounds__(OCT_IDX_THREADS) void ft_index_oct_kernel(const int32_t *__restrict__ idx0,
+__global__ __launch_bounds__(OCT_IDX_THREADS, 6) void ft_index_oct_kernel(const int32_t *__restrict__ idx0,
                                                                        const int32_t *__restrict__ idx1, int batch, int nnz,
                                                                        int cols, int chunks_per_input, int fbits,
                                                                        uint2 *__restrict__ stream,
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(OCT_IDX_THREADS) void ft_index_oct_kernel(const int
     const int eps = 64 / slot, sub = lane / slot, li = lane % slot;
     const int per_wave = (n_e + NW - 1) / NW;
     const int e_lo = wave * per_wave, e_hi = min(n_e, e_lo + per_wave);
-    constexpr int IDX_REG = 8;  // 512 threads: 32 entries per wave, 2 entries per step at nnz = 32
+    constexpr int IDX_REG = 16;  // 512 threads: 32 entries per wave, 2 entries per step at nnz = 32 -> all in registers
     const int nsteps = (per_wave + eps - 1) / eps;
     auto load_j = [&](int e) -> int {
         if constexpr (GRP) {
@@ -1503,12 +1505,6 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds_any(const float *__res
                                          chunks_per_input, chunks_per_wg, gp);
 }
 
-#ifdef BT_OCT_TIMING  // developer build (tools/oct_timing.py): cycles per phase of workgroup 0, one row per wave
-__device__ unsigned long long bt_oct_dbg[16 * 8];
-#define OT(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); bt_oct_dbg[(threadIdx.x >> 6) * 8 + (i)] += t_ - t_last; t_last = t_; } } while (0)
-#else
-#define OT(i) do { } while (0)
-#endif
 // Backward over the octet index (ft_index_oct_kernel): same workgroup shape and staging as ft_bwd_lds_body above --
 // dW tile of 32 rows accumulating in LDS, the activated gradient tile of a chunk staged once -- but the reduction
 // walks per-wave streams: each 8-lane group sums ONE run (or part of a long run) at a time, the eight groups of a
@@ -1671,16 +1667,10 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
     }
     uint2 cur_fix = make_uint2(0u, 0u);
     uint32_t cur_nfix = 0;
-#ifdef BT_OCT_TIMING
-    unsigned long long t_last = __builtin_readcyclecounter();
-#endif
-    OT(0);
     for (int c = c_lo; c < c_hi; c++) {
         const int kc = GRP ? 0 : c / chunks_per_input;
         const int n_e = r_ne;
-        OT(1);
         lds_barrier();  // the previous chunk's readers are done with gt; its parts are complete
-        OT(2);
         // this wave's stream of the chunk: rows [r0, r0 + n), n a multiple of 4; the first two 4-row sets now
         const int r0 = __builtin_amdgcn_readfirstlane((int)p_r0), n = __builtin_amdgcn_readfirstlane((int)p_r1) - r0;
         const uint2 *sp = stream + ((size_t)c * rows_cap + r0) * 8 + rg_e;
@@ -1737,11 +1727,8 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
                 bsum.x += g.x, bsum.y += g.y, bsum.z += g.z, bsum.w += g.w;
             }
         }
-        OT(3);
         lds_barrier();
-        OT(4);
         prefetch(min(c + 1, c_hi - 1));  // (the last chunk fetches itself again: unconditional on purpose, see above)
-        OT(5);
 
         float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         const char *gb = reinterpret_cast<const char *>(gt) + rg_s * 16;
@@ -1780,10 +1767,8 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
             if (t + 4 < n) row(qb0), row(qb1), row(qb2), row(qb3);
             fetch(t + 12, qb0, qb1, qb2, qb3);
         }
-        OT(6);
     }
     __syncthreads();
-    OT(7);
     fixup(cur_fix, cur_nfix);
     __syncthreads();
     float *pw = partial_w + (size_t)cg * tc * d.stride;
@@ -2428,14 +2413,6 @@ int bt_internal_ft_build_sorted(void *stream, const bt_ft_desc *d, const int32_t
     return BT_OK;
 }
 
-#ifdef BT_OCT_TIMING
-extern "C" int bt_oct_debug_read(unsigned long long *out) {
-    BT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(bt_oct_dbg), sizeof(unsigned long long) * 128));
-    unsigned long long z[128] = {0};
-    BT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(bt_oct_dbg), z, sizeof(z)));
-    return 0;
-}
-#endif
 // tests change the switches between cases of one process: they call this after touching the environment
 extern "C" void bt_internal_reload_env(void) { g_ft_env.reload(); }
 
