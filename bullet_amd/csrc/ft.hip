@@ -708,21 +708,19 @@ __global__ __launch_bounds__(OCT_IDX_THREADS, 6) void ft_index_oct_kernel(const 
     uint32_t *start = cnt + (size_t)wave * cols;
     uint16_t *s16 = reinterpret_cast<uint16_t *>(my_stream);
     const uint32_t in_mask = (4u << ls) - 1;
+    // The entries of a step take their slots one entry after the other (a wave's LDS operations execute in order), so
+    // a run holds its pairs in ascending entry order whatever the lanes do inside one atomic; equal features inside
+    // ONE list share the entry, so their order among themselves does not matter. `start` is this wave's own cursor row.
     auto place_step = [&](int e, int jraw) {
         const int nvalid = n_valid(e, jraw);
         const int j = jraw - col0;
         const bool active = (e < e_hi) && (li < nvalid) && in_seg(j);
-        unsigned long long peers = __ballot(active);
-        for (int bit = 0; bit < fbits; bit++) {
-            const unsigned long long bb = __ballot(active && ((j >> bit) & 1));
-            peers &= ((j >> bit) & 1) ? bb : ~bb;
-        }
+        uint32_t i = 0;
+        for (int q = 0; q < eps; q++)
+            if (active && sub == q) i = atomicAdd(&start[j], 1u);
         if (active) {
-            const int rank = __popcll(peers & lt_mask), count = __popcll(peers);
-            const uint32_t base = start[j], i = base + rank;
             const uint32_t within = i & in_mask;
             s16[itembase[item0[j] + (i >> (ls + 2))] + (within >> 2) * 32 + (within & 3)] = (uint16_t)(e << 7);
-            if (rank == count - 1) start[j] = base + count;
         }
     };
 #pragma unroll
