@@ -268,6 +268,7 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
         upload(0, 0, stream)
     lib.check(L.bt_event_record(uploaded[0], stream))
     counter = [0]
+    landed = C.c_int(0)
 
     def step():
         i = counter[0]
@@ -288,13 +289,15 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
         if multi_layer:  # its index structures are built during this step, once the upload has landed
             net.hint_next(dev_batches[nxt], uploaded[nxt] if args.upload != "none" else None)
         if args.upload != "none":
-            L.bt_stream_wait_event(stream, uploaded[cur])
+            L.bt_event_query(uploaded[cur], C.byref(landed))
+            if not landed.value:  # (the usual case: the upload was enqueued a whole step ago -- no wait packet then)
+                L.bt_stream_wait_event(stream, uploaded[cur])
         net.forward_backward(dev_batches[cur], stream)
         if comm is not None:
             net.dp_step(comm, adj, lr, stream)  # exchange (grads + loss slot) and optimiser, replicas stay identical
+            L.bt_event_record(consumed[cur], stream)
         else:
-            net.optimiser_step(adj, lr, stream)
-        L.bt_event_record(consumed[cur], stream)
+            net.optimiser_step(adj, lr, stream, consumed[cur])  # `consumed` rides on the update kernel's packet
 
     def release():
         torch.cuda.synchronize()

@@ -735,10 +735,23 @@ static int opt_lookahead(bt_net *n, void *stream) {
 }
 
 int bt_net_optimiser_step(bt_net *n, void *stream, const float *adj_dev, const float *lr_dev) {
+    return bt_net_optimiser_step_event(n, stream, adj_dev, lr_dev, nullptr);
+}
+
+int bt_net_optimiser_step_event(bt_net *n, void *stream, const float *adj_dev, const float *lr_dev, void *done_event) {
     BT_REQUIRE(n, "bt_net_optimiser_step: null net");
     if (n->opt_kind != BT_OPT_ADAMW) n->opt_step++;  // RAdam::update / RangerLookahead::update count their calls (radam.rs:277, ranger.rs:88)
-    if (int rc = opt_apply(n, stream, n->n_tensors, n->adam, adj_dev, lr_dev)) return rc;
-    return opt_lookahead(n, stream);
+    hipEvent_t done = static_cast<hipEvent_t>(done_event);
+    const bool lookahead = n->opt_kind == BT_OPT_RANGER && n->opt_step % n->opt_k == 0;
+    // the event rides on the update kernel's own dispatch packet: a separate record costs the stream a few microseconds
+    if (done && !lookahead) bt_attach_stop_event(BTK_ADAMW, done);
+    if (int rc = opt_apply(n, stream, n->n_tensors, n->adam, adj_dev, lr_dev)) {
+        if (done && !lookahead) (void)bt_take_stop_event(BTK_ADAMW);  // not launched: do not leave the event armed
+        return rc;
+    }
+    if (int rc = opt_lookahead(n, stream)) return rc;
+    if (done && lookahead) BT_HIP(hipEventRecord(done, bt_stream(stream)));
+    return BT_OK;
 }
 
 // ---- data-parallel step (section 7 of the header; no counterpart in the reference)

@@ -253,6 +253,17 @@ int bt_event_sync(void *event) {
     return BT_OK;
 }
 
+int bt_event_query(void *event, int *done) {
+    BT_REQUIRE(event && done, "bt_event_query: null argument");
+    const hipError_t e = hipEventQuery(static_cast<hipEvent_t>(event));
+    if (e != hipSuccess && e != hipErrorNotReady) {
+        bt_set_error("%s: %s", hipGetErrorName(e), hipGetErrorString(e));
+        return BT_ERR_HIP;
+    }
+    *done = e == hipSuccess;
+    return BT_OK;
+}
+
 int bt_stream_wait_event(void *stream, void *event) {
     BT_REQUIRE(event, "bt_stream_wait_event: null event");
     BT_HIP(hipStreamWaitEvent(bt_stream(stream), static_cast<hipEvent_t>(event), 0));

@@ -765,8 +765,10 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
             const bt_batch nb = dev_batch(nset);
             TRY(bt_net_hint_next_batch(net, &nb, uploaded[nset]));
         }
-        // compute waits for this batch's upload; the learning rate goes through a pinned ring (run.rs:171-173)
-        TRY_HIP(hipStreamWaitEvent(bt_stream(compute_stream), uploaded[set], 0));
+        // compute waits for this batch's upload -- no wait packet when it has landed already (the usual case: it was
+        // enqueued a whole step ago); the learning rate goes through a pinned ring (run.rs:171-173)
+        if (hipEventQuery(uploaded[set]) != hipSuccess)
+            TRY_HIP(hipStreamWaitEvent(bt_stream(compute_stream), uploaded[set], 0));
         // (a copy only when this ring slot does not hold the value yet: every packet on the compute stream costs a
         // few microseconds of bubble, and most schedules change the rate once per superbatch or never)
         const float lr_now = (cfg->lr_fn ? cfg->lr_fn(cfg->sched_user, batch, sb) : bt_lr_at(&cfg->lr, batch, sb));
@@ -794,8 +796,9 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
             TRY(sync(bt_net_grads(net), bt_net_flat_size(net) + (loss_slot ? 1 : 0)));
             if (!loss_slot) TRY(sync(loss_at, 1));
         }
-        if (!(dp && comm)) TRY(bt_net_optimiser_step(net, compute_stream, adj_dev, lr_dev + ring));
-        TRY_HIP(hipEventRecord(consumed[set], bt_stream(compute_stream)));
+        // `consumed` travels on the update kernel's dispatch packet (single device)
+        if (!(dp && comm)) TRY(bt_net_optimiser_step_event(net, compute_stream, adj_dev, lr_dev + ring, consumed[set]));
+        else TRY_HIP(hipEventRecord(consumed[set], bt_stream(compute_stream)));
         if (dp) TRY(bt_memcpy_d2h_async(loss_host + ring, loss_at, sizeof(float), compute_stream));
         TRY_HIP(hipEventRecord(loss_ready[ring], bt_stream(compute_stream)));
         pending.push_back({sb, batch});

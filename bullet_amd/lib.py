@@ -141,7 +141,7 @@ SYMBOLS = [
     "bt_version", "bt_last_error",
     "bt_device_count", "bt_device_set", "bt_device_props", "bt_device_sync", "bt_malloc", "bt_free",
     "bt_host_alloc_pinned", "bt_host_free_pinned", "bt_stream_create", "bt_stream_destroy", "bt_stream_sync",
-    "bt_event_create", "bt_event_destroy", "bt_event_record", "bt_stream_wait_event", "bt_event_sync",
+    "bt_event_create", "bt_event_destroy", "bt_event_record", "bt_stream_wait_event", "bt_event_sync", "bt_event_query",
     "bt_memset_async", "bt_memcpy_h2d_async", "bt_memcpy_d2h_async", "bt_memcpy_d2d_async",
     "bt_profile_start", "bt_profile_set_filter", "bt_profile_set_sampling", "bt_profile_stop", "bt_profile_num_kernels", "bt_profile_kernel_name",
     "bt_ft_forward", "bt_ft_backward_workspace_bytes", "bt_ft_backward", "bt_ft_build_index",
@@ -153,7 +153,7 @@ SYMBOLS = [
     "bt_net_param_count", "bt_net_num_tensors", "bt_net_tensor_size", "bt_net_tensor_offset", "bt_net_create",
     "bt_net_destroy", "bt_net_params", "bt_net_grads", "bt_net_momentum", "bt_net_velocity", "bt_net_set_adamw",
     "bt_net_flat_size", "bt_net_max_batch", "bt_net_grads_owned", "bt_chessboard_from_str", "bt_measure_loader_throughput", "bt_reader_open_viribinpack", "bt_reader_open_sfbinpack",
-    "bt_net_forward_backward", "bt_net_optimiser_step", "bt_net_forward", "bt_net_hint_next_batch",
+    "bt_net_forward_backward", "bt_net_optimiser_step", "bt_net_optimiser_step_event", "bt_net_forward", "bt_net_hint_next_batch",
     "bt_input_init", "bt_input_num_inputs", "bt_input_max_active", "bt_map_batch", "bt_map_batch_device", "bt_map_batch_device_errors",
     "bt_net_init_weights_host", "bt_lr_at", "bt_wdl_at", "bt_reader_open", "bt_reader_next", "bt_reader_close",
     "bt_train_run",
@@ -204,6 +204,7 @@ def load():
     L.bt_event_destroy.argtypes = [C.c_void_p]
     L.bt_event_record.argtypes = [C.c_void_p, C.c_void_p]
     L.bt_event_sync.argtypes = [C.c_void_p]
+    L.bt_event_query.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.bt_stream_wait_event.argtypes = [C.c_void_p, C.c_void_p]
     L.bt_memset_async.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
     for f in ("bt_memcpy_h2d_async", "bt_memcpy_d2h_async", "bt_memcpy_d2d_async"):
@@ -253,6 +254,7 @@ def load():
     L.bt_net_forward_backward.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.c_void_p]
     L.bt_net_hint_next_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p]
     L.bt_net_optimiser_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bt_net_optimiser_step_event.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bt_net_forward.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]
     L.bt_input_init.argtypes = [C.POINTER(InputDesc), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
     L.bt_input_num_inputs.argtypes = [C.POINTER(InputDesc)]
@@ -553,7 +555,7 @@ class Net:
             raise comm.errors[0]
         check(rc)
 
-    def optimiser_step(self, adj_dev, lr_dev, stream=None):
+    def optimiser_step(self, adj_dev, lr_dev, stream=None, done_event=None):
         import torch
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
-        check(self.L.bt_net_optimiser_step(self.h, s, adj_dev.data_ptr(), lr_dev.data_ptr()))
+        check(self.L.bt_net_optimiser_step_event(self.h, s, adj_dev.data_ptr(), lr_dev.data_ptr(), done_event))

@@ -78,6 +78,7 @@ int bt_event_destroy(void *event);
 int bt_event_record(void *event, void *stream);
 int bt_stream_wait_event(void *stream, void *event);
 int bt_event_sync(void *event); /* the host waits until the recorded work is done */
+int bt_event_query(void *event, int *done); /* *done = 1 if it is (never blocks) */
 /* stream_memset / stream_memcpy_h2d / stream_memcpy_d2h, bindings.rs:110-125 */
 int bt_memset_async(void *ptr, int byte_value, size_t bytes, void *stream);
 int bt_memcpy_h2d_async(void *dst, const void *src_host, size_t bytes, void *stream);
@@ -336,6 +337,9 @@ int bt_net_forward_backward(bt_net *net, void *stream, const bt_batch *batch, fl
 int bt_net_hint_next_batch(bt_net *net, const bt_batch *next, void *ready_event);
 /* AdamW on every tensor with g = adj * grad (adj = 1/global_batch), adam.rs:121-131 */
 int bt_net_optimiser_step(bt_net *net, void *stream, const float *adj_dev, const float *lr_dev);
+/* the same, and `done_event` (a hipEvent_t, may be NULL) fires when the update is complete. It travels on the update
+ * kernel's own dispatch packet, which is cheaper for the stream than a bt_event_record behind the call. */
+int bt_net_optimiser_step_event(bt_net *net, void *stream, const float *adj_dev, const float *lr_dev, void *done_event);
 /* Which OptimiserState the step uses: AdamW (default, adam.rs), RAdam (radam.rs) or Ranger = RAdam + lookahead
  * (ranger.rs; defaults beta1 0.99, alpha 0.5, k 6; the slow weights start at ZERO as in the reference, ranger.rs:71).
  * Resets the step counter and the optimiser state (OptimiserState::reset). Per-tensor decay / betas / clip stay
