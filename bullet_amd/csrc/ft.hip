@@ -1866,7 +1866,7 @@ __global__ __launch_bounds__(256) void ft_bwd_merge_head(const float *__restrict
         }
         return;
     }
-    const int hb = blockIdx.x - blocks_w;  // head blocks: dW1 elements, then one block for db1 and the loss
+    const int hb = blockIdx.x - blocks_w;  // head blocks: dW1 elements, then one block each for the loss and db1[m]
     const int blocks_1 = (hm.n1 + 255) / 256;
     if (hb < blocks_1) {
         const int e = hb * 256 + threadIdx.x;
@@ -1878,22 +1878,20 @@ __global__ __launch_bounds__(256) void ft_bwd_merge_head(const float *__restrict
         }
         return;
     }
-    // last block: the loss sum and db1[m] from the finishing kernel's per-workgroup partials -- thread t takes
-    // partials t, t + 256, ... in order, then a fixed tree over the threads
+    // last 1 + w1_rows blocks, one sum each: the loss (m = -1) and db1[m], from the finishing kernel's per-workgroup
+    // partials -- thread t takes partials t, t + 256, ... in order, then a fixed tree over the threads
     __shared__ float red[256];
-    for (int m = -1; m < hm.w1_rows; m++) {  // m = -1: the loss
-        float s = 0.0f;
-        for (int i = threadIdx.x; i < hm.n_loss_partials; i += 256)
-            s += m < 0 ? hm.loss_partials[i] : hm.gz_parts[(size_t)i * hm.w1_rows + m];
-        red[threadIdx.x] = s;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) (m < 0 ? hm.loss_sum : hm.db1 + m)[0] = red[0];
+    const int m = hb - blocks_1 - 1;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < hm.n_loss_partials; i += 256)
+        s += m < 0 ? hm.loss_partials[i] : hm.gz_parts[(size_t)i * hm.w1_rows + m];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
+    if (threadIdx.x == 0) (m < 0 ? hm.loss_sum : hm.db1 + m)[0] = red[0];
 }
 
 // segment-grouped merge: dw[seg*tc + f] = sum over the segment's backward items of their slabs (item order = list
@@ -2193,7 +2191,8 @@ int ft_backward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, 
         const FtHeadMerge hm{reinterpret_cast<const float *>(ws + p.off_pw1), p.pw1_stride, head->dw1, head->db1,
                              head->gz_parts, head->loss_partials, head->n_loss_partials, head->loss_sum, fs.w1_rows,
                              p.chunks_per_input / p.chunks_per_wg, n1};
-        BT_LAUNCH(BTK_FT_BWD_MERGE, s, ft_bwd_merge_head, dim3(blocks_w + bt_div_up(n1, 256) + 1), dim3(256), 0, pw, pb, dw,
+        BT_LAUNCH(BTK_FT_BWD_MERGE, s, ft_bwd_merge_head, dim3(blocks_w + bt_div_up(n1, 256) + 1 + fs.w1_rows), dim3(256), 0,
+                  pw, pb, dw,
                   dbias, *d, p.G, hm, blocks_w);
     } else if (p.grouped)
         BT_LAUNCH(BTK_FT_BWD_MERGE, s, ft_bwd_merge_grp, dim3(bt_div_up(n, 256)), dim3(256), 0, pw, pb, dw, dbias, *d, p.tc,
