@@ -292,12 +292,12 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
             L.bt_event_query(uploaded[cur], C.byref(landed))
             if not landed.value:  # (the usual case: the upload was enqueued a whole step ago -- no wait packet then)
                 L.bt_stream_wait_event(stream, uploaded[cur])
-        net.forward_backward(dev_batches[cur], stream)
         if comm is not None:
+            net.forward_backward(dev_batches[cur], stream)
             net.dp_step(comm, adj, lr, stream)  # exchange (grads + loss slot) and optimiser, replicas stay identical
             L.bt_event_record(consumed[cur], stream)
-        else:
-            net.optimiser_step(adj, lr, stream, consumed[cur])  # `consumed` rides on the update kernel's packet
+        else:  # fwd + bwd + AdamW; `consumed` rides on the last kernel's packet
+            net.train_step(dev_batches[cur], adj, lr, stream, consumed[cur])
 
     def release():
         torch.cuda.synchronize()

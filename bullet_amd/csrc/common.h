@@ -144,12 +144,33 @@ int bt_internal_head_finish(void *stream, const bt_dense_desc *d, const float *z
 // head: optional. When given (and bt_internal_ft_fused_head_grad_ok), the FT backward also produces the head's own
 // gradients from the activation tile it stages -- dw1, db1 (from gz_parts [n_loss_partials][head_rows], the
 // per-workgroup sums bt_internal_head_finish leaves) and the final loss sum -- and no other kernel has to.
+// `step`: AdamW applied to every gradient element right where the merge kernel has just formed it (the lowered
+// training step of a single device, bt_net_train_step): tensors l0w, l0b, l1w, l1b whose .grad pointers are dw, dbias,
+// dw1, db1; adj / lr as in bt_adamw. The gradients are still written.
+struct bt_ft_fused_adamw {
+    bt_adamw_tensor t[4];
+    const float *adj, *lr;
+};
 struct bt_ft_head_grads {
     float *dw1, *db1;
     const float *gz_parts, *loss_partials;
     int n_loss_partials;
     float *loss_sum;
+    const bt_ft_fused_adamw *step = nullptr;
+    hipEvent_t done = nullptr;  // rides on the merge kernel's dispatch packet
 };
+// AdamW on one element: adam.rs:43-51, in this exact order (shared by adamw_kernel and the fused merge)
+// No fma contraction: the op is inlined into two kernels and must round the same way in both (and as the CPU oracle,
+// built with -ffp-contract=off, does).
+__device__ __forceinline__ void bt_adam_op(float grad, float rate, float &p, float &m, float &v, const bt_adamw_tensor &t) {
+#pragma clang fp contract(off)
+    p *= 1.0f - t.decay * rate;
+    m = t.beta1 * m + (1.0f - t.beta1) * grad;
+    v = t.beta2 * v + (1.0f - t.beta2) * grad * grad;
+    const float val = m / (__fsqrt_rn(v) + 0.00000001f);
+    p -= rate * val;
+    p = fminf(fmaxf(p, t.min_weight), t.max_weight);
+}
 bool bt_internal_ft_fused_head_grad_ok(const bt_ft_desc *d, int head_rows);
 int bt_internal_ft_backward_fused(void *stream, const bt_ft_desc *d, const float *gz, const float *w1,
                                   const int32_t *bucket, int head_rows, const float *out, const float *saved, float *dw,

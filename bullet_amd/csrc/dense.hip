@@ -323,17 +323,6 @@ struct AdamTable {
 };
 constexpr int ADAM_ELEMS_PER_BLOCK = 1024;  // 256 threads x float4
 
-__device__ __forceinline__ void adam_op(float grad, float rate, float &p, float &m, float &v,
-                                        const bt_adamw_tensor &t) {
-    // adam.rs:43-51, in this exact order
-    p *= 1.0f - t.decay * rate;
-    m = t.beta1 * m + (1.0f - t.beta1) * grad;
-    v = t.beta2 * v + (1.0f - t.beta2) * grad * grad;
-    const float val = m / (__fsqrt_rn(v) + 0.00000001f);
-    p -= rate * val;
-    p = fminf(fmaxf(p, t.min_weight), t.max_weight);
-}
-
 // radam.rs:35-52, in this exact order
 __device__ __forceinline__ void radam_op(float grad, float rate, int denom, float &p, float &m, float &v,
                                          const bt_adamw_tensor &t) {
@@ -377,17 +366,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamTable tab, const float *
         float4 m = *reinterpret_cast<float4 *>(t.momentum + e0);
         float4 v = *reinterpret_cast<float4 *>(t.velocity + e0);
         const float4 g = *reinterpret_cast<const float4 *>(t.grad + e0);
-        adam_op(adj * g.x, rate, p.x, m.x, v.x, t);
-        adam_op(adj * g.y, rate, p.y, m.y, v.y, t);
-        adam_op(adj * g.z, rate, p.z, m.z, v.z, t);
-        adam_op(adj * g.w, rate, p.w, m.w, v.w, t);
+        bt_adam_op(__fmul_rn(adj, g.x), rate, p.x, m.x, v.x, t);
+        bt_adam_op(__fmul_rn(adj, g.y), rate, p.y, m.y, v.y, t);
+        bt_adam_op(__fmul_rn(adj, g.z), rate, p.z, m.z, v.z, t);
+        bt_adam_op(__fmul_rn(adj, g.w), rate, p.w, m.w, v.w, t);
         *reinterpret_cast<float4 *>(t.param + e0) = p;
         *reinterpret_cast<float4 *>(t.momentum + e0) = m;
         *reinterpret_cast<float4 *>(t.velocity + e0) = v;
     } else {
         for (size_t e = e0; e < t.n && e < e0 + 4; e++) {
             float p = t.param[e], m = t.momentum[e], v = t.velocity[e];
-            adam_op(adj * t.grad[e], rate, p, m, v, t);
+            bt_adam_op(__fmul_rn(adj, t.grad[e]), rate, p, m, v, t);
             t.param[e] = p, t.momentum[e] = m, t.velocity[e] = v;
         }
     }

@@ -1841,11 +1841,21 @@ struct FtHeadMerge {
     float *loss_sum;
     int w1_rows, groups_per_input, n1;  // n1 = n_inputs * out_w * w1_rows floats of dW1
 };
+// STEP: AdamW on each element as soon as its gradient is complete (bt_ft_fused_adamw: tensor i's buffers are
+// indexed like its gradient: dw, dbias, dw1, db1) -- the same bt_adam_op on the same values as adamw_kernel.
+template <bool STEP>
 __global__ __launch_bounds__(256) void ft_bwd_merge_head(const float *__restrict__ partial_w,
                                                          const float *__restrict__ partial_b, float *__restrict__ dw,
                                                          float *__restrict__ dbias, bt_ft_desc d, int G, FtHeadMerge hm,
-                                                         int blocks_w) {
+                                                         int blocks_w, bt_ft_fused_adamw st) {
     const int rows4 = d.rows / 4;
+    float adj = 0.0f, rate = 0.0f;
+    if constexpr (STEP) adj = st.adj[0], rate = st.lr[0];
+    auto update = [&](const bt_adamw_tensor &t, size_t i, float g) {
+        float p = t.param[i], m = t.momentum[i], v = t.velocity[i];
+        bt_adam_op(__fmul_rn(adj, g), rate, p, m, v, t);
+        t.param[i] = p, t.momentum[i] = m, t.velocity[i] = v;
+    };
     if ((int)blockIdx.x < blocks_w) {
         const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
         const long long nw = (long long)d.cols * rows4;
@@ -1858,11 +1868,25 @@ __global__ __launch_bounds__(256) void ft_bwd_merge_head(const float *__restrict
                 s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
             }
             *reinterpret_cast<float4 *>(dw + o) = s;
+            if constexpr (STEP) {
+                const bt_adamw_tensor &t0 = st.t[0];
+                float4 p = *reinterpret_cast<const float4 *>(t0.param + o);
+                float4 m = *reinterpret_cast<const float4 *>(t0.momentum + o);
+                float4 v = *reinterpret_cast<const float4 *>(t0.velocity + o);
+                bt_adam_op(__fmul_rn(adj, s.x), rate, p.x, m.x, v.x, t0);
+                bt_adam_op(__fmul_rn(adj, s.y), rate, p.y, m.y, v.y, t0);
+                bt_adam_op(__fmul_rn(adj, s.z), rate, p.z, m.z, v.z, t0);
+                bt_adam_op(__fmul_rn(adj, s.w), rate, p.w, m.w, v.w, t0);
+                *reinterpret_cast<float4 *>(t0.param + o) = p;
+                *reinterpret_cast<float4 *>(t0.momentum + o) = m;
+                *reinterpret_cast<float4 *>(t0.velocity + o) = v;
+            }
         } else if (dbias && t < nw + d.rows) {
             const int r = (int)(t - nw);
             float s = 0.0f;
             for (int g = 0; g < G; g++) s += partial_b[(size_t)g * d.rows + r];
             dbias[r] = s;
+            if constexpr (STEP) update(st.t[1], (size_t)r, s);
         }
         return;
     }
@@ -1875,6 +1899,7 @@ __global__ __launch_bounds__(256) void ft_bwd_merge_head(const float *__restrict
             float s = 0.0f;
             for (int g = k * hm.groups_per_input; g < (k + 1) * hm.groups_per_input; g++) s += hm.pw1[(size_t)g * hm.pw1_stride + e];
             hm.dw1[e] = s;
+            if constexpr (STEP) update(st.t[2], (size_t)e, s);
         }
         return;
     }
@@ -1891,7 +1916,11 @@ __global__ __launch_bounds__(256) void ft_bwd_merge_head(const float *__restrict
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) (m < 0 ? hm.loss_sum : hm.db1 + m)[0] = red[0];
+    if (threadIdx.x == 0) {
+        (m < 0 ? hm.loss_sum : hm.db1 + m)[0] = red[0];
+        if constexpr (STEP)
+            if (m >= 0) update(st.t[3], (size_t)m, red[0]);
+    }
 }
 
 // segment-grouped merge: dw[seg*tc + f] = sum over the segment's backward items of their slabs (item order = list
@@ -2191,9 +2220,19 @@ int ft_backward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, 
         const FtHeadMerge hm{reinterpret_cast<const float *>(ws + p.off_pw1), p.pw1_stride, head->dw1, head->db1,
                              head->gz_parts, head->loss_partials, head->n_loss_partials, head->loss_sum, fs.w1_rows,
                              p.chunks_per_input / p.chunks_per_wg, n1};
-        BT_LAUNCH(BTK_FT_BWD_MERGE, s, ft_bwd_merge_head, dim3(blocks_w + bt_div_up(n1, 256) + 1 + fs.w1_rows), dim3(256), 0,
-                  pw, pb, dw,
-                  dbias, *d, p.G, hm, blocks_w);
+        const dim3 mgrid(blocks_w + bt_div_up(n1, 256) + 1 + fs.w1_rows);
+        BT_REQUIRE(!head->step || (d->rows == d->stride && d->offset == 0 && dbias && head->step->t[0].grad == dw &&
+                                   head->step->t[1].grad == dbias && head->step->t[2].grad == head->dw1 &&
+                                   head->step->t[3].grad == head->db1),
+                   "bt_ft_backward(fused step): the optimiser tensors do not match the gradient buffers");
+        if (head->done) bt_attach_stop_event(BTK_FT_BWD_MERGE, head->done);
+        if (head->step) {
+            BT_LAUNCH(BTK_FT_BWD_MERGE, s, ft_bwd_merge_head<true>, mgrid, dim3(256), 0, pw, pb, dw, dbias, *d, p.G, hm,
+                      blocks_w, *head->step);
+        } else {
+            BT_LAUNCH(BTK_FT_BWD_MERGE, s, ft_bwd_merge_head<false>, mgrid, dim3(256), 0, pw, pb, dw, dbias, *d, p.G, hm,
+                      blocks_w, bt_ft_fused_adamw{});
+        }
     } else if (p.grouped)
         BT_LAUNCH(BTK_FT_BWD_MERGE, s, ft_bwd_merge_grp, dim3(bt_div_up(n, 256)), dim3(256), 0, pw, pb, dw, dbias, *d, p.tc,
                   reinterpret_cast<const int *>(ws + p.off_segitems), reinterpret_cast<const int *>(ws + p.off_counts));

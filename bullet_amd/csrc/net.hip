@@ -502,7 +502,34 @@ int bt_net_forward(bt_net *n, void *stream, const bt_batch *b, float *out_dev, f
     return BT_OK;
 }
 
+namespace {
+struct StepOpt {  // bt_net_train_step: the optimiser step that follows, for the paths that can fuse it
+    const float *adj, *lr;
+    hipEvent_t done;
+    bool stepped = false;
+};
+int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *loss_sum_dev, StepOpt *opt);
+}  // namespace
+
 int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *loss_sum_dev) {
+    return forward_backward_impl(n, stream, b, loss_sum_dev, nullptr);
+}
+
+// run.rs:185-192 for one device: forward, backward and the optimiser update of one batch. Where the gradient merge of
+// the feature transformer is the last kernel of the backward pass (single-layer head, AdamW, no factoriser), AdamW runs
+// inside it, element by element as each gradient sum completes; otherwise this is bt_net_forward_backward followed by
+// bt_net_optimiser_step_event. The gradients are written either way, and the results are bit-identical.
+int bt_net_train_step(bt_net *n, void *stream, const bt_batch *b, float *loss_sum_dev, const float *adj_dev,
+                      const float *lr_dev, void *done_event) {
+    BT_REQUIRE(adj_dev && lr_dev, "bt_net_train_step: null adj / lr");
+    StepOpt opt{adj_dev, lr_dev, static_cast<hipEvent_t>(done_event)};
+    if (int rc = forward_backward_impl(n, stream, b, loss_sum_dev, &opt)) return rc;
+    if (opt.stepped) return BT_OK;
+    return bt_net_optimiser_step_event(n, stream, adj_dev, lr_dev, done_event);
+}
+
+namespace {
+int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *loss_sum_dev, StepOpt *opt) {
     if (int rc = check_batch(n, b, "bt_net_forward_backward")) return rc;
     BT_REQUIRE(loss_sum_dev, "bt_net_forward_backward: null loss buffer");
     hipStream_t s = bt_stream(stream);
@@ -579,8 +606,14 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
         // beside its LDS-bound reduction), and its merge kernel adds up the head's bias gradient and the loss from
         // the finishing kernel's partials: no second stream, no second pass over the [B][2H] activations.
         n->has_next = false;
-        const bt_ft_head_grads hg{n->grads + n->t_off[2], n->grads + n->t_off[3], n->gz_parts, n->loss_partials,
-                                  n->n_loss_partials, loss_sum_dev};
+        bt_ft_head_grads hg{n->grads + n->t_off[2], n->grads + n->t_off[3], n->gz_parts, n->loss_partials,
+                            n->n_loss_partials, loss_sum_dev};
+        bt_ft_fused_adamw fa;
+        if (opt && n->opt_kind == BT_OPT_ADAMW && n->d.ft_factoriser <= 0 && n->n_tensors == 4) {
+            for (int t = 0; t < 4; t++) fa.t[t] = n->adam[t];
+            fa.adj = opt->adj, fa.lr = opt->lr;
+            hg.step = &fa, hg.done = opt->done, opt->stepped = true;
+        }
         if (int rc = bt_internal_ft_backward_fused(s, &f, n->gz0, n->params + n->t_off[2],
                                                    n->d.dense_bucketed[0] ? b->buckets : nullptr, q0.buckets, n->hid,
                                                    n->saved, n->grads + n->t_off[0], n->grads + n->t_off[1], n->ft_ws,
@@ -651,6 +684,7 @@ int bt_net_forward_backward(bt_net *n, void *stream, const bt_batch *b, float *l
     if (int rc = factor_reduce()) return rc;
     return prepare_next(n);
 }
+}  // namespace
 
 int bt_net_hint_next_batch(bt_net *n, const bt_batch *next, void *ready_event) {
     BT_REQUIRE(n, "bt_net_hint_next_batch: null net");

@@ -782,7 +782,11 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
         // single device: the step writes its loss sum straight into the pinned (device-visible) host ring -- one
         // 4-byte store over PCIe instead of a copy packet on the compute stream
         float *loss_at = loss_slot ? bt_net_grads(net) + bt_net_flat_size(net) : dp ? loss_dev + ring : loss_host + ring;
-        TRY(bt_net_forward_backward(net, compute_stream, &bb, loss_at));
+        if (!dp) {  // single device: one call, the update fused into the backward where the net allows it
+            TRY(bt_net_train_step(net, compute_stream, &bb, loss_at, adj_dev, lr_dev + ring, consumed[set]));
+        } else {
+            TRY(bt_net_forward_backward(net, compute_stream, &bb, loss_at));
+        }
         if (dp && comm) {  // exchange + optimiser in one call: RCCL from C, the table sharded when it is large
             TRY(bt_net_dp_step(net, comm, compute_stream, adj_dev, lr_dev + ring, cfg->dp_shard_min_floats));
         } else if (dp) {
@@ -796,9 +800,8 @@ extern "C" int bt_train_run(bt_net *net, const bt_input_desc *input, const bt_tr
             TRY(sync(bt_net_grads(net), bt_net_flat_size(net) + (loss_slot ? 1 : 0)));
             if (!loss_slot) TRY(sync(loss_at, 1));
         }
-        // `consumed` travels on the update kernel's dispatch packet (single device)
-        if (!(dp && comm)) TRY(bt_net_optimiser_step_event(net, compute_stream, adj_dev, lr_dev + ring, consumed[set]));
-        else TRY_HIP(hipEventRecord(consumed[set], bt_stream(compute_stream)));
+        if (dp && !comm) TRY(bt_net_optimiser_step_event(net, compute_stream, adj_dev, lr_dev + ring, consumed[set]));
+        else if (dp) TRY_HIP(hipEventRecord(consumed[set], bt_stream(compute_stream)));
         if (dp) TRY(bt_memcpy_d2h_async(loss_host + ring, loss_at, sizeof(float), compute_stream));
         TRY_HIP(hipEventRecord(loss_ready[ring], bt_stream(compute_stream)));
         pending.push_back({sb, batch});

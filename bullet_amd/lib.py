@@ -153,7 +153,7 @@ SYMBOLS = [
     "bt_net_param_count", "bt_net_num_tensors", "bt_net_tensor_size", "bt_net_tensor_offset", "bt_net_create",
     "bt_net_destroy", "bt_net_params", "bt_net_grads", "bt_net_momentum", "bt_net_velocity", "bt_net_set_adamw",
     "bt_net_flat_size", "bt_net_max_batch", "bt_net_grads_owned", "bt_chessboard_from_str", "bt_measure_loader_throughput", "bt_reader_open_viribinpack", "bt_reader_open_sfbinpack",
-    "bt_net_forward_backward", "bt_net_optimiser_step", "bt_net_optimiser_step_event", "bt_net_forward", "bt_net_hint_next_batch",
+    "bt_net_forward_backward", "bt_net_optimiser_step", "bt_net_optimiser_step_event", "bt_net_train_step", "bt_net_forward", "bt_net_hint_next_batch",
     "bt_input_init", "bt_input_num_inputs", "bt_input_max_active", "bt_map_batch", "bt_map_batch_device", "bt_map_batch_device_errors",
     "bt_net_init_weights_host", "bt_lr_at", "bt_wdl_at", "bt_reader_open", "bt_reader_next", "bt_reader_close",
     "bt_train_run",
@@ -255,6 +255,7 @@ def load():
     L.bt_net_hint_next_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p]
     L.bt_net_optimiser_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bt_net_optimiser_step_event.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bt_net_train_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bt_net_forward.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]
     L.bt_input_init.argtypes = [C.POINTER(InputDesc), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
     L.bt_input_num_inputs.argtypes = [C.POINTER(InputDesc)]
@@ -539,6 +540,13 @@ class Net:
         import torch
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
         check(self.L.bt_net_forward_backward(self.h, s, C.byref(batch), self.loss.data_ptr()))
+
+    def train_step(self, batch, adj_dev, lr_dev, stream=None, done_event=None):
+        """bt_net_train_step: forward + backward + optimiser update of one batch (single device)"""
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        check(self.L.bt_net_train_step(self.h, s, C.byref(batch), self.loss.data_ptr(), adj_dev.data_ptr(),
+                                       lr_dev.data_ptr(), done_event))
 
     def hint_next(self, batch, ready=None):
         """bt_net_hint_next_batch: `batch` is what the step after the coming one uses; its tensors are complete now, or

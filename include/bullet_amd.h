@@ -340,6 +340,12 @@ int bt_net_optimiser_step(bt_net *net, void *stream, const float *adj_dev, const
 /* the same, and `done_event` (a hipEvent_t, may be NULL) fires when the update is complete. It travels on the update
  * kernel's own dispatch packet, which is cheaper for the stream than a bt_event_record behind the call. */
 int bt_net_optimiser_step_event(bt_net *net, void *stream, const float *adj_dev, const float *lr_dev, void *done_event);
+/* One training step of a single device = run.rs:185-192: bt_net_forward_backward + bt_net_optimiser_step_event in one
+ * call, bit-identical to the two calls. For the single-layer nets whose backward pass ends in the feature transformer's
+ * gradient merge (AdamW, no factoriser) the update runs inside that merge kernel, element by element as each gradient
+ * sum completes -- one kernel and one pass over the parameters fewer. The flat gradient is still filled. */
+int bt_net_train_step(bt_net *net, void *stream, const bt_batch *batch, float *loss_sum_dev, const float *adj_dev,
+                      const float *lr_dev, void *done_event);
 /* Which OptimiserState the step uses: AdamW (default, adam.rs), RAdam (radam.rs) or Ranger = RAdam + lookahead
  * (ranger.rs; defaults beta1 0.99, alpha 0.5, k 6; the slow weights start at ZERO as in the reference, ranger.rs:71).
  * Resets the step counter and the optimiser state (OptimiserState::reset). Per-tensor decay / betas / clip stay

@@ -230,6 +230,10 @@ pub mod ffi {
         ) -> c_int;
         pub fn bt_net_hint_next_batch(net: *mut bt_net, next: *const bt_batch, ready_event: *mut c_void) -> c_int;
         pub fn bt_net_optimiser_step(net: *mut bt_net, stream: *mut c_void, adj_dev: *const f32, lr_dev: *const f32) -> c_int;
+        pub fn bt_net_train_step(
+            net: *mut bt_net, stream: *mut c_void, batch: *const bt_batch, loss_sum_dev: *mut f32, adj_dev: *const f32,
+            lr_dev: *const f32, done_event: *mut c_void,
+        ) -> c_int;
         pub fn bt_net_optimiser_step_event(
             net: *mut bt_net, stream: *mut c_void, adj_dev: *const f32, lr_dev: *const f32, done_event: *mut c_void,
         ) -> c_int;

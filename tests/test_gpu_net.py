@@ -175,6 +175,44 @@ def test_net_step_vs_oracle(name):
         gu.assert_close(a, b, rtol=1e-4, atol=2e-5, what=f"{name}: tensor {t} after 4 steps")
 
 
+@pytest.mark.parametrize("name", ["cfg2_buckets", "cfg1_simple", "factoriser_single_layer", "cfg3_multilayer"])
+def test_train_step_is_forward_backward_plus_optimiser_step(name):
+    """bt_net_train_step (the update fused into the gradient merge where the net allows it: cfg2 / cfg1) writes the
+    bits of bt_net_forward_backward + bt_net_optimiser_step: losses, gradients, parameters, momentum, velocity."""
+    cfg, (kind, layout, fact), nb, ft_eff = NETS[name]
+    batches = fixture_batches(kind, layout, fact, nb, 0.75, 2, batch=4096 if name == "cfg2_buckets" else 1500)
+    B = batches[0][0].shape[0]
+    params = ob.net_init(ob.make_net(**cfg), 198273612, ft_eff)
+    adj, lrd = torch.tensor([1.0 / B], device="cuda"), torch.tensor([0.001], device="cuda")
+    done = C.c_void_p()
+    lib.check(L.bt_event_create(C.byref(done)))
+    res = []
+    for fused in (False, True):
+        net = lib.Net(lib.make_net_desc(**cfg), B)
+        net.set_params(params)
+        lib.check(L.bt_net_set_adamw(net.h, 0, 0.01, 0.9, 0.999, -0.99, 0.99))
+        losses = []
+        for s in range(3):
+            stm, ntm, bk, tg, w = batches[s % len(batches)]
+            tb = net.make_batch(gu.dev(stm), gu.dev(ntm), gu.dev(bk), gu.dev(tg), gu.dev(w))
+            if fused:
+                net.train_step(tb, adj, lrd, done_event=done)
+                lib.check(L.bt_event_sync(done))  # fires when the update is complete
+            else:
+                net.forward_backward(tb)
+                net.optimiser_step(adj, lrd)
+                torch.cuda.synchronize()
+            losses.append(net.loss.item())
+        res.append((losses, net.get_tensors(net.grads), net.get_tensors(net.params), net.state_view("momentum"),
+                    net.state_view("velocity")))
+        net.close()
+    L.bt_event_destroy(done)
+    assert res[0][0] == res[1][0]
+    for a, b in zip(res[0][1:], res[1][1:]):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+
+
 @pytest.mark.parametrize("name", ["wdl_softmax_ce", "wdl_bucketed_multilayer", "power_loss"])
 def test_other_loss_functions_net_vs_oracle(name):
     """wdl_output nets (3 outputs, softmax cross-entropy on one-hot W/D/L targets, value.rs:96-101) and the
