@@ -14,7 +14,7 @@ timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out
 cp "$(find $out/trace -name '*kernel_stats.csv' | head -1)" $out/kernel_stats.csv
 rm -rf $out/trace
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py $args --steps 6 --warmup 2 --no-profile > $out/pmc_$c.log 2>&1
+  timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py $args --steps 6 --warmup 2 --no-profile --spinup-ms 0 > $out/pmc_$c.log 2>&1
   cp "$(find $out/pmc_$c -name '*counter_collection.csv' | head -1)" $out/$c.csv
   rm -rf $out/pmc_$c
 done
