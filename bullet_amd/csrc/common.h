@@ -197,7 +197,12 @@ size_t bt_internal_dense_tail_workspace_bytes(const bt_dense_desc *q1);
 int bt_internal_dense_tail(void *stream, const bt_dense_desc *q1, const bt_dense_desc *q2, const float *w2, const float *b2,
                            const float *w3, const float *b3, const float *a1, const float *targets, const float *ew,
                            float *y, float *ga1, float *dw2, float *db2, float *dw3, float *db3, float *loss_sum,
-                           void *workspace, size_t workspace_bytes);
+                           void *workspace, size_t workspace_bytes, int act_before = -1);
+// act_before >= 0: ga1 receives the gradient w.r.t. the PRE-activation of the layer before the tail (its activation's
+// derivative applied here); that layer's bt_dense_backward must then run between bt_internal_dense_set_gz_ready(true)
+// and (false), and only if bt_internal_dense_takes_gz(desc) says its path forms gz in a kernel of its own
+bool bt_internal_dense_takes_gz(const bt_dense_desc *d);
+void bt_internal_dense_set_gz_ready(bool on);
 // dense head forward fused with sigmoid-MSE: writes y, grad_y, per-workgroup loss partials and (optionally) gz_out =
 // grad_y * f'(y), the gradient w.r.t. the layer's pre-activation
 int bt_internal_dense_forward_loss(void *stream, const bt_dense_desc *d, const float *w, const float *bias,

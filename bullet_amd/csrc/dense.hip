@@ -716,6 +716,9 @@ struct DensePermTab {
     int max_items = 0;
 };
 thread_local DensePermTab g_dense_tab;
+// set by net.hip around a bt_dense_backward whose grad_y already is the gradient w.r.t. the layer's pre-activation
+// (the fused tail formed it): the mid-size paths then skip dense_gz_kernel
+thread_local bool g_dense_gy_is_gz = false;
 constexpr int BP_THREADS = 1024;
 constexpr int DX_CH = 64;  // positions per item = 4 waves x one 16-row MFMA tile
 
@@ -982,6 +985,9 @@ struct TailArgs {
     float *y, *ga1;                     // net output [B], gradient w.r.t. a1 [B][n1]
     float *part;                        // [max_items][tail_part_floats]
     int n1, n2, nb, act2, act3;
+    int act1;                           // >= 0: ga1 receives gradient * f'(a1) of that activation, i.e. the gradient
+                                        // w.r.t. the pre-activation of the layer before (its backward then skips
+                                        // dense_gz_kernel); -1: the gradient w.r.t. a1 itself
 };
 __host__ __device__ inline int tail_part_floats(int n1, int n2) { return n2 * n1 + 2 * n2 + 2; }  // dW2 db2 dW3 db3 loss
 
@@ -1054,6 +1060,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void dense_tail_kernel(TailArgs A, De
         if (p < cnt) {
             float sacc = 0.0f;
             for (int o = 0; o < n2; o++) sacc += W2[o * n1 + i] * g2[p * l2 + o];
+            if (A.act1 >= 0) sacc = sacc * bt_act_deriv(A.act1, a1[p * l1 + i]);  // = dense_gz_kernel's one multiply
             A.ga1[(size_t)s_pos[p] * n1 + i] = sacc;
         }
     }
@@ -1572,7 +1579,7 @@ size_t bt_internal_dense_tail_workspace_bytes(const bt_dense_desc *q1) {
 int bt_internal_dense_tail(void *stream, const bt_dense_desc *q1, const bt_dense_desc *q2, const float *w2, const float *b2,
                            const float *w3, const float *b3, const float *a1, const float *targets, const float *ew,
                            float *y, float *ga1, float *dw2, float *db2, float *dw3, float *db3, float *loss_sum,
-                           void *workspace, size_t workspace_bytes) {
+                           void *workspace, size_t workspace_bytes, int act_before) {
     BT_REQUIRE(bt_internal_dense_tail_ok(q1, q2), "dense_tail: shape not supported");
     BT_REQUIRE(g_dense_tab.items, "dense_tail: no bucket permutation installed");
     BT_REQUIRE(w2 && b2 && w3 && b3 && a1 && targets && y && ga1 && dw2 && db2 && dw3 && db3 && loss_sum && workspace,
@@ -1580,7 +1587,8 @@ int bt_internal_dense_tail(void *stream, const bt_dense_desc *q1, const bt_dense
     BT_REQUIRE(workspace_bytes >= bt_internal_dense_tail_workspace_bytes(q1), "dense_tail: workspace too small");
     const DensePermTab tab = g_dense_tab;
     const int n1 = q1->in, n2 = q1->out, nb = q1->buckets;
-    TailArgs A{w2, b2, w3, b3, a1, targets, ew, y, ga1, static_cast<float *>(workspace), n1, n2, nb, q1->act, q2->act};
+    TailArgs A{w2, b2, w3, b3, a1, targets, ew, y, ga1, static_cast<float *>(workspace), n1, n2, nb, q1->act, q2->act,
+               act_before};
     const size_t lds = ((size_t)n2 * n1 + 2 * n2 + DX_CH * (n1 + 1) + 2 * DX_CH * (n2 + 1) + 2 * DX_CH) * sizeof(float);
     hipStream_t s = bt_stream(stream);
     if (int rc = dense_set_lds(dense_tail_kernel, lds)) return rc;
@@ -1590,6 +1598,11 @@ int bt_internal_dense_tail(void *stream, const bt_dense_desc *q1, const bt_dense
               A.part, n1, n2, nb, dw2, db2, dw3, db3, loss_sum, tab);
     BT_LAUNCH_CHECK();
     return BT_OK;
+}
+
+void bt_internal_dense_set_gz_ready(bool on) { g_dense_gy_is_gz = on; }
+bool bt_internal_dense_takes_gz(const bt_dense_desc *d) {
+    return dense_validate(d, "dense_takes_gz") == BT_OK && !dense_bwd_small_ok(d) && (dense_mid_ok(d) || dense_tiny_ok(d));
 }
 
 void bt_internal_dense_set_perm(void *buf, int batch, int nb) {
@@ -1711,9 +1724,13 @@ int bt_dense_backward(void *stream, const bt_dense_desc *d, const float *w, cons
         float *gz = reinterpret_cast<float *>(ws + bt_align((size_t)nrm * rows * d->in * sizeof(float)) +
                                               bt_align((size_t)nrm * rows * sizeof(float)));
         const size_t ngz = (size_t)d->batch * d->out;
-        BT_LAUNCH(BTK_DENSE_BWD_DX, s, dense_gz_kernel, dim3(bt_div_up((long long)ngz, 256)), dim3(256), 0, y, grad_y, gz, ngz,
-                  d->act);
-        BT_LAUNCH_CHECK();
+        if (g_dense_gy_is_gz) {
+            gz = const_cast<float *>(grad_y);  // (read only below)
+        } else {
+            BT_LAUNCH(BTK_DENSE_BWD_DX, s, dense_gz_kernel, dim3(bt_div_up((long long)ngz, 256)), dim3(256), 0, y, grad_y, gz,
+                      ngz, d->act);
+            BT_LAUNCH_CHECK();
+        }
         if (!tiny && dense_mfma_ok(d) && g_dense_tab.items &&
             (size_t)g_dense_tab.max_items * 16 * d->in <= (size_t)nrm * rows * d->in) {
             const DensePermTab tab = g_dense_tab;

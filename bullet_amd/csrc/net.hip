@@ -576,6 +576,9 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
     const bool tail = L == 3 && perm.built && n->d.loss_kind == BT_LOSS_SIGMOID_MSE && !has_skip(&n->d) &&
                       !has_post(&n->d, 0) && !has_post(&n->d, 1) && n->d.dense_bucketed[1] && n->d.dense_bucketed[2] &&
                       bt_internal_dense_tail_ok(&q1, &q_last);
+    // the tail can hand layer 0 the gradient w.r.t. its pre-activation directly (one multiply more in the tail kernel,
+    // one elementwise kernel less on the critical path)
+    const bool tail_gz = tail && !bt_internal_dense_head_ok(&q0) && bt_internal_dense_takes_gz(&q0);
     if (int rc = forward_impl(n, s, b, fuse_loss && !tail, side_head, head_in_ft && !ready, true, perm.built && !ready,
                               tail ? 1 : -1))
         return rc;
@@ -584,7 +587,8 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
                                             n->params + n->t_off[6], n->params + n->t_off[7], n->a[0], b->targets,
                                             n->d.use_entry_weights ? b->entry_weights : nullptr, n->a[2], n->ga[0],
                                             n->grads + n->t_off[4], n->grads + n->t_off[5], n->grads + n->t_off[6],
-                                            n->grads + n->t_off[7], loss_sum_dev, n->dense_ws, n->dense_ws_bytes))
+                                            n->grads + n->t_off[7], loss_sum_dev, n->dense_ws, n->dense_ws_bytes,
+                                            tail_gz ? n->d.dense_act[0] : -1))
             return rc;
     } else if (!fuse_loss)
         if (int rc = bt_loss(s, n->d.loss_kind, b->batch, n->d.dense_out[L - 1], net_output(n), b->targets,
@@ -667,9 +671,13 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
                                                          loss_here ? n->loss_partials : nullptr, n->n_loss_partials,
                                                          loss_sum_dev, n->dense_ws, n->dense_ws_bytes, false))
                 return rc;
-        } else if (int rc = bt_dense_backward(s, &q, wk, x, b->buckets, n->a[k], gy, dwk, dbk, gx, n->dense_ws,
-                                              n->dense_ws_bytes))
-            return rc;
+        } else {
+            bt_internal_dense_set_gz_ready(k == 0 && tail_gz);
+            const int rc = bt_dense_backward(s, &q, wk, x, b->buckets, n->a[k], gy, dwk, dbk, gx, n->dense_ws,
+                                             n->dense_ws_bytes);
+            bt_internal_dense_set_gz_ready(false);
+            if (rc) return rc;
+        }
     }
     if (!ready) BT_HIP(hipStreamWaitEvent(s, n->ev_index, 0));  // join
     if (fuse_ft) {
