@@ -159,6 +159,17 @@ struct bt_ft_head_grads {
     const bt_ft_fused_adamw *step = nullptr;
     hipEvent_t done = nullptr;  // rides on the merge kernel's dispatch packet
 };
+// The same for nets whose backward pass ends in ft_bwd_merge / ft_bwd_merge_grp (multi-layer nets): the table and its
+// bias are updated where their gradients are merged, the other tensors (their gradients are complete before the FT
+// backward starts) by extra blocks of the same launch. Armed for the calling thread's next LDS-path FT backward.
+struct bt_ft_step_all {
+    bt_ft_fused_adamw base;  // t[0] = table, t[1] = FT bias
+    int n_extra;
+    bt_adamw_tensor extra[BT_ADAMW_MAX_TENSORS];
+    hipEvent_t done;  // rides on the merge kernel's dispatch packet (may be null)
+};
+bool bt_internal_ft_step_ok(const bt_ft_desc *d);
+void bt_internal_ft_arm_step(const bt_ft_step_all *step);
 // AdamW on one element: adam.rs:43-51, in this exact order (shared by adamw_kernel and the fused merge)
 // No fma contraction: the op is inlined into two kernels and must round the same way in both (and as the CPU oracle,
 // built with -ffp-contract=off, does).

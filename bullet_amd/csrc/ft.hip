@@ -1951,6 +1951,95 @@ __global__ __launch_bounds__(256) void ft_bwd_merge_grp(const float *__restrict_
     }
 }
 
+// ft_bwd_merge / ft_bwd_merge_grp with the optimiser step inside (bt_ft_step_all): blocks [0, blocks_w) merge the table
+// and bias gradients and apply AdamW to those elements at once; the blocks behind them are adamw_kernel's, for the
+// other tensors of the net. Same bt_adam_op on the same values as the separate launch: bit-identical.
+struct FtStepTab {
+    bt_adamw_tensor t0, t1;
+    const float *adj, *lr;
+    int n_extra;
+    int block_start[BT_ADAMW_MAX_TENSORS + 1];  // prefix sum of 1024-element blocks per extra tensor
+    bt_adamw_tensor extra[BT_ADAMW_MAX_TENSORS];
+};
+template <bool GRP>
+__global__ __launch_bounds__(256) void ft_bwd_merge_step(const float *__restrict__ partial_w,
+                                                         const float *__restrict__ partial_b, float *__restrict__ dw,
+                                                         float *__restrict__ dbias, bt_ft_desc d, int tc_or_g,
+                                                         const int *__restrict__ seg_items,
+                                                         const int *__restrict__ counts, int blocks_w, FtStepTab st) {
+    const float adj = st.adj[0], rate = st.lr[0];
+    if ((int)blockIdx.x >= blocks_w) {  // the other tensors: adamw_kernel's body
+        const int xb = blockIdx.x - blocks_w;
+        int ti = 0;
+        while (ti + 1 < st.n_extra && xb >= st.block_start[ti + 1]) ti++;
+        const bt_adamw_tensor &t = st.extra[ti];
+        const size_t e0 = ((size_t)(xb - st.block_start[ti]) * 256 + threadIdx.x) * 4;
+        if (e0 >= t.n) return;
+        if (e0 + 4 <= t.n && (t.n % 4 == 0)) {
+            float4 p = *reinterpret_cast<float4 *>(t.param + e0);
+            float4 m = *reinterpret_cast<float4 *>(t.momentum + e0);
+            float4 v = *reinterpret_cast<float4 *>(t.velocity + e0);
+            const float4 g = *reinterpret_cast<const float4 *>(t.grad + e0);
+            bt_adam_op(__fmul_rn(adj, g.x), rate, p.x, m.x, v.x, t);
+            bt_adam_op(__fmul_rn(adj, g.y), rate, p.y, m.y, v.y, t);
+            bt_adam_op(__fmul_rn(adj, g.z), rate, p.z, m.z, v.z, t);
+            bt_adam_op(__fmul_rn(adj, g.w), rate, p.w, m.w, v.w, t);
+            *reinterpret_cast<float4 *>(t.param + e0) = p;
+            *reinterpret_cast<float4 *>(t.momentum + e0) = m;
+            *reinterpret_cast<float4 *>(t.velocity + e0) = v;
+        } else {
+            for (size_t e = e0; e < t.n && e < e0 + 4; e++) {
+                float p = t.param[e], m = t.momentum[e], v = t.velocity[e];
+                bt_adam_op(__fmul_rn(adj, t.grad[e]), rate, p, m, v, t);
+                t.param[e] = p, t.momentum[e] = m, t.velocity[e] = v;
+            }
+        }
+        return;
+    }
+    const int rows4 = d.rows / 4;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nw = (long long)d.cols * rows4;
+    if (t < nw) {
+        const int f = (int)(t / rows4), r = (int)(t % rows4) * 4;
+        const size_t o = (size_t)f * d.stride + d.offset + r;  // (stride == rows, offset == 0: host-checked)
+        float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if constexpr (GRP) {
+            const int tc = tc_or_g, sg = f / tc, fl = f - sg * tc;
+            const size_t ol = (size_t)fl * d.stride + d.offset + r;
+            for (int g = seg_items[sg]; g < seg_items[sg + 1]; g++) {
+                const float4 v = *reinterpret_cast<const float4 *>(partial_w + (size_t)g * tc * d.stride + ol);
+                s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+            }
+        } else {
+            for (int g = 0; g < tc_or_g; g++) {
+                const float4 v = *reinterpret_cast<const float4 *>(partial_w + (size_t)g * d.cols * d.stride + o);
+                s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+            }
+        }
+        *reinterpret_cast<float4 *>(dw + o) = s;
+        const bt_adamw_tensor &t0 = st.t0;
+        float4 p = *reinterpret_cast<const float4 *>(t0.param + o);
+        float4 m = *reinterpret_cast<const float4 *>(t0.momentum + o);
+        float4 v = *reinterpret_cast<const float4 *>(t0.velocity + o);
+        bt_adam_op(__fmul_rn(adj, s.x), rate, p.x, m.x, v.x, t0);
+        bt_adam_op(__fmul_rn(adj, s.y), rate, p.y, m.y, v.y, t0);
+        bt_adam_op(__fmul_rn(adj, s.z), rate, p.z, m.z, v.z, t0);
+        bt_adam_op(__fmul_rn(adj, s.w), rate, p.w, m.w, v.w, t0);
+        *reinterpret_cast<float4 *>(t0.param + o) = p;
+        *reinterpret_cast<float4 *>(t0.momentum + o) = m;
+        *reinterpret_cast<float4 *>(t0.velocity + o) = v;
+    } else if (t < nw + d.rows) {
+        const int r = (int)(t - nw), G = GRP ? counts[1] : tc_or_g;
+        float s = 0.0f;
+        for (int g = 0; g < G; g++) s += partial_b[(size_t)g * d.rows + r];
+        dbias[r] = s;
+        const bt_adamw_tensor &t1 = st.t1;
+        float p = t1.param[r], m = t1.momentum[r], v = t1.velocity[r];
+        bt_adam_op(__fmul_rn(adj, s), rate, p, m, v, t1);
+        t1.param[r] = p, t1.momentum[r] = m, t1.velocity[r] = v;
+    }
+}
+
 // dw[f][offset + r] = sum_g partial_w[g][f][offset + r] (fixed order); dbias likewise
 __global__ __launch_bounds__(256) void ft_bwd_merge(const float *__restrict__ partial_w,
                                                     const float *__restrict__ partial_b, float *__restrict__ dw,
@@ -2139,6 +2228,8 @@ FtGrp ft_grp(const FtPlan &p, char *ws, bool fwd) {
                  reinterpret_cast<const int4 *>(ws + p.off_chunks), counts, counts + 3, p.tc};
 }
 
+thread_local const bt_ft_step_all *tl_step = nullptr;  // bt_internal_ft_arm_step
+
 int ft_backward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, const float *grad_out, FtFusedSrc fs,
                            const float *out, const float *saved, const uint16_t *sorted, const uint32_t *offs, char *ws,
                            float *dw, float *dbias, const bt_ft_head_grads *head = nullptr) {
@@ -2233,6 +2324,29 @@ int ft_backward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, 
             BT_LAUNCH(BTK_FT_BWD_MERGE, s, ft_bwd_merge_head<false>, mgrid, dim3(256), 0, pw, pb, dw, dbias, *d, p.G, hm,
                       blocks_w, bt_ft_fused_adamw{});
         }
+    } else if (const bt_ft_step_all *step = tl_step) {
+        tl_step = nullptr;
+        BT_REQUIRE(d->rows == d->stride && d->offset == 0 && dbias && step->base.t[0].grad == dw &&
+                       step->base.t[1].grad == dbias && step->n_extra >= 0 && step->n_extra <= BT_ADAMW_MAX_TENSORS,
+                   "bt_ft_backward(fused step): the optimiser tensors do not match the gradient buffers");
+        FtStepTab st;
+        st.t0 = step->base.t[0], st.t1 = step->base.t[1], st.adj = step->base.adj, st.lr = step->base.lr;
+        st.n_extra = step->n_extra;
+        int xb = 0;
+        for (int i = 0; i < step->n_extra; i++) {
+            st.block_start[i] = xb, st.extra[i] = step->extra[i];
+            xb += bt_div_up((long long)step->extra[i].n, 1024);
+        }
+        st.block_start[step->n_extra] = xb;
+        const int blocks_w = bt_div_up(n, 256);
+        if (step->done) bt_attach_stop_event(BTK_FT_BWD_MERGE, step->done);
+        if (p.grouped)
+            BT_LAUNCH(BTK_FT_BWD_MERGE, s, ft_bwd_merge_step<true>, dim3(blocks_w + xb), dim3(256), 0, pw, pb, dw, dbias, *d,
+                      p.tc, reinterpret_cast<const int *>(ws + p.off_segitems),
+                      reinterpret_cast<const int *>(ws + p.off_counts), blocks_w, st);
+        else
+            BT_LAUNCH(BTK_FT_BWD_MERGE, s, ft_bwd_merge_step<false>, dim3(blocks_w + xb), dim3(256), 0, pw, pb, dw, dbias, *d,
+                      p.G, nullptr, nullptr, blocks_w, st);
     } else if (p.grouped)
         BT_LAUNCH(BTK_FT_BWD_MERGE, s, ft_bwd_merge_grp, dim3(bt_div_up(n, 256)), dim3(256), 0, pw, pb, dw, dbias, *d, p.tc,
                   reinterpret_cast<const int *>(ws + p.off_segitems), reinterpret_cast<const int *>(ws + p.off_counts));
@@ -2243,6 +2357,13 @@ int ft_backward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, 
 }
 
 }  // namespace
+
+void bt_internal_ft_arm_step(const bt_ft_step_all *step) { tl_step = step; }
+bool bt_internal_ft_step_ok(const bt_ft_desc *d) {
+    FtPlan p;
+    if (ft_validate(d, "ft_step_ok") || ft_plan(d, &p)) return false;
+    return p.lds_path && !force_generic() && d->rows == d->stride && d->offset == 0;
+}
 
 // ---- internal (not part of the public header): FT backward fed by a one-output dense head, used by net.hip
 bool bt_internal_ft_fused_ok(const bt_ft_desc *d, int head_rows) {

@@ -680,6 +680,22 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
         }
     }
     if (!ready) BT_HIP(hipStreamWaitEvent(s, n->ev_index, 0));  // join
+    // bt_net_train_step: AdamW inside the FT gradient merge (table + bias) and, by extra blocks of that launch, for the
+    // other tensors, whose gradients are complete by now
+    bt_ft_step_all step_all;
+    struct Disarm {  // whatever path leaves this function: no armed step (it points into this frame) survives it
+        ~Disarm() { bt_internal_ft_arm_step(nullptr); }
+    } disarm;
+    if (opt && n->opt_kind == BT_OPT_ADAMW && n->d.ft_factoriser <= 0 && n->n_tensors - 2 <= BT_ADAMW_MAX_TENSORS &&
+        bt_internal_ft_step_ok(&f)) {
+        step_all.base.t[0] = n->adam[0], step_all.base.t[1] = n->adam[1];
+        step_all.base.adj = opt->adj, step_all.base.lr = opt->lr;
+        step_all.n_extra = n->n_tensors - 2;
+        for (int t = 2; t < n->n_tensors; t++) step_all.extra[t - 2] = n->adam[t];
+        step_all.done = opt->done;
+        bt_internal_ft_arm_step(&step_all);
+        opt->stepped = true;
+    }
     if (fuse_ft) {
         if (int rc = bt_internal_ft_backward_fused(s, &f, n->gz0, n->params + n->t_off[2],
                                                    n->d.dense_bucketed[0] ? b->buckets : nullptr, q0.buckets, n->hid,
