@@ -5,7 +5,10 @@ import csv
 import sys
 
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+# a step ends with the optimiser update: adamw_kernel, or the merge kernel that carries it (bt_net_train_step)
 ad = [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"]]
+if len(ad) < 2:
+    ad = [i for i, r in enumerate(rows) if "ft_bwd_merge" in r["Kernel_Name"]]
 a, b = ad[-2], ad[-1]
 t0 = prev_end = int(rows[a]["End_Timestamp"])
 for r in rows[a + 1:b + 1]:
