@@ -881,15 +881,6 @@ __device__ __forceinline__ void fwd_gather_slot(int lane, int &entry, int &slot)
     else q = 3, sl = m - 24;
     entry = h * 4 + q, slot = sl;
 }
-__device__ __forceinline__ int fwd_gather_lane(int entry, int slot) {
-    const int q = entry & 3, h = entry >> 2;
-    int m;
-    if (q == 0) m = slot < 4 ? slot : slot + 8;
-    else if (q == 1) m = 20 + slot;
-    else if (q == 2) m = 4 + slot;
-    else m = slot < 4 ? 16 + slot : 24 + slot;
-    return h * 32 + m;
-}
 __host__ __device__ constexpr int fwd_strip_words(int nround) { return nround * 32 + 4; }  // +4: bank skew
 
 // HEAD: a one-output dense head (Matmul + Select of one row per position, matmul.rs:62-93, select.rs:12-26) is
@@ -902,6 +893,14 @@ struct FtHeadSink {
     int w1_rows;            // = number of output buckets (one output each)
     float *zpart;           // [n_inputs * ntiles][batch]
 };
+
+// The lane holding part gs ^ 4 of the same entry (fwd_gather_slot's map keeps an entry's two quads inside one 16-lane
+// row, 4 or 12 lanes apart): two DPP row rotations and a select instead of a ds_bpermute through the LDS pipe.
+__device__ __forceinline__ float fwd_partner(float v, int lane) {
+    const float r4 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, true));   // from lane - 4
+    const float r12 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x12C, 0xF, 0xF, true));  // from lane + 4
+    return (lane & 4) ? r12 : r4;
+}
 
 __device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lanes of an aligned quad, on every lane
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
@@ -1117,9 +1116,8 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
         }
         if constexpr (PAIR) {
             // the lane holding part gs^4 of the same entry has the other factors of the same output columns
-            const int partner = fwd_gather_lane(ge, gs ^ 4);
-            const float4 o = make_float4(__shfl(c.x, partner), __shfl(c.y, partner), __shfl(c.z, partner),
-                                         __shfl(c.w, partner));
+            const float4 o = make_float4(fwd_partner(c.x, lane), fwd_partner(c.y, lane), fwd_partner(c.z, lane),
+                                         fwd_partner(c.w, lane));
             const float4 pr = make_float4(c.x * o.x, c.y * o.y, c.z * o.z, c.w * o.w);
             if (live) {
                 *reinterpret_cast<float4 *>(saved + (size_t)e * d.rows + row) = c;
@@ -1139,7 +1137,7 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
                 float p = 0.0f;
                 p += c.x * wv.x, p += c.y * wv.y, p += c.z * wv.z, p += c.w * wv.w;
                 p = quad_sum(p);  // columns 0-15 on the quad gs < 4, 16-31 on the other
-                const float hi = __shfl(p, fwd_gather_lane(ge, gs ^ 4));
+                const float hi = fwd_partner(p, lane);
                 if (live && gs == 0) hs.zpart[(size_t)(k * ntiles + rt) * d.batch + b] = p + hi;
             }
         }
