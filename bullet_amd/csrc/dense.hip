@@ -478,7 +478,14 @@ __global__ __launch_bounds__(HF_THREADS) void head_finish_kernel(const float *__
     if (b < d.batch) {
         float z = 0.0f;
         int p = 0;
-        for (; p + 16 <= nparts; p += 16) {  // 16 loads in flight, added in ascending order
+        for (; p + 32 <= nparts; p += 32) {  // 32 loads in flight (the kernel is their latency), added in ascending order
+            float v[32];
+#pragma unroll
+            for (int u = 0; u < 32; u++) v[u] = zpart[(size_t)(p + u) * d.batch + b];
+#pragma unroll
+            for (int u = 0; u < 32; u++) z += v[u];
+        }
+        for (; p + 16 <= nparts; p += 16) {
             float v[16];
 #pragma unroll
             for (int u = 0; u < 16; u++) v[u] = zpart[(size_t)(p + u) * d.batch + b];
