@@ -213,6 +213,44 @@ def test_train_step_is_forward_backward_plus_optimiser_step(name):
             np.testing.assert_array_equal(x, y)
 
 
+def test_event_primitives_order_streams_and_report_completion():
+    """bt_event_* / bt_stream_wait_event (section 1 of the header): a copy on one stream, a dependent copy on another,
+    bt_event_query / bt_event_sync on the host; bt_net_optimiser_step_event fires its event after the update"""
+    s1, s2, e1, e2 = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    for h, make in ((s1, L.bt_stream_create), (s2, L.bt_stream_create), (e1, L.bt_event_create), (e2, L.bt_event_create)):
+        lib.check(make(C.byref(h)))
+    n = 1 << 22
+    src = torch.arange(n, dtype=torch.float32, device="cuda")
+    mid, dst = torch.zeros_like(src), torch.zeros_like(src)
+    torch.cuda.synchronize()
+    lib.check(L.bt_memcpy_d2d_async(mid.data_ptr(), src.data_ptr(), n * 4, s1))
+    lib.check(L.bt_event_record(e1, s1))
+    lib.check(L.bt_stream_wait_event(s2, e1))  # s2 may not read `mid` before s1 has written it
+    lib.check(L.bt_memcpy_d2d_async(dst.data_ptr(), mid.data_ptr(), n * 4, s2))
+    lib.check(L.bt_event_record(e2, s2))
+    lib.check(L.bt_event_sync(e2))
+    done = C.c_int(0)
+    lib.check(L.bt_event_query(e1, C.byref(done)))
+    assert done.value == 1 and torch.equal(dst, src)
+    assert L.bt_event_record(None, s1) != 0 and L.bt_event_query(e1, None) != 0
+    # the optimiser step's completion event
+    cfg = NETS["cfg1_simple"][0]
+    net = lib.Net(lib.make_net_desc(**cfg), 64)
+    net.init_weights()
+    net.grads.fill_(1.0)
+    before = net.params.clone()
+    adj, lrd = torch.tensor([1.0], device="cuda"), torch.tensor([0.01], device="cuda")
+    torch.cuda.synchronize()
+    net.optimiser_step(adj, lrd, stream=s1.value, done_event=e1)
+    lib.check(L.bt_event_sync(e1))
+    assert not torch.equal(net.params, before)
+    net.close()
+    for ev in (e1, e2):
+        lib.check(L.bt_event_destroy(ev))
+    for st in (s1, s2):
+        lib.check(L.bt_stream_destroy(st))
+
+
 @pytest.mark.parametrize("name", ["wdl_softmax_ce", "wdl_bucketed_multilayer", "power_loss"])
 def test_other_loss_functions_net_vs_oracle(name):
     """wdl_output nets (3 outputs, softmax cross-entropy on one-hot W/D/L targets, value.rs:96-101) and the
