@@ -712,7 +712,7 @@ constexpr int DM_OH = 8;        // output rows per workgroup, dW
 // Positions sorted by output bucket (stable) for the kernels below: with real data every chunk of consecutive
 // positions holds all the buckets, and a chunk re-stages the bucket's 64 KiB of weights once per bucket present;
 // walking the batch in bucket order makes that once per chunk. net.hip builds the permutation once per step
-// (bucket_perm_kernel) and installs it for the calling thread; the public bt_dense_* entry points run without.
+// (bucket_count_kernel + bucket_place_kernel) and installs it for the calling thread; the public bt_dense_* entry points run without.
 // The same kernel cuts the sorted order into bucket-pure items of <= DX_CH positions {bucket, start, count}; the
 // 16-output layers then run as small f32 GEMMs on the matrix cores, one item per workgroup (dense_mfma_*).
 struct DensePermTab {
@@ -721,67 +721,79 @@ struct DensePermTab {
     const int *bucket_items = nullptr;  // [nb + 1] item range of each bucket
     const int *counts = nullptr;    // [0] number of items
     int max_items = 0;
+    int *blk_cnt = nullptr;         // scratch of the two-kernel build: [ceil(batch / BPC_BLOCK)][nb] block histograms
 };
 thread_local DensePermTab g_dense_tab;
 // set by net.hip around a bt_dense_backward whose grad_y already is the gradient w.r.t. the layer's pre-activation
 // (the fused tail formed it): the mid-size paths then skip dense_gz_kernel
 thread_local bool g_dense_gy_is_gz = false;
-constexpr int BP_THREADS = 1024;
 constexpr int DX_CH = 64;  // positions per item = 4 waves x one 16-row MFMA tile
 
-__global__ __launch_bounds__(BP_THREADS) void bucket_perm_kernel(const int32_t *__restrict__ bucket, int batch, int nb,
+// Stable counting sort of the positions by output bucket in two multi-workgroup kernels (the segment grouping of
+// ft.hip has the same shape): per-block histograms, then every block sums the histograms of the blocks before it for
+// itself -- nblk * nb integers that sit in L2 -- ranks its positions with one ballot per bucket and places them;
+// block 0 also cuts the order into bucket-pure items of DX_CH positions. Same order as a serial stable sort.
+constexpr int BPC_BLOCK = 256;
+__global__ __launch_bounds__(BPC_BLOCK) void bucket_count_kernel(const int32_t *__restrict__ bucket, int batch, int nb,
+                                                                 int *__restrict__ blk_cnt) {
+    __shared__ int hist[16];
+    if ((int)threadIdx.x < nb) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int p = blockIdx.x * BPC_BLOCK + threadIdx.x;
+    if (p < batch) atomicAdd(&hist[min(max(bucket[p], 0), nb - 1)], 1);
+    __syncthreads();
+    if ((int)threadIdx.x < nb) blk_cnt[(size_t)blockIdx.x * nb + threadIdx.x] = hist[threadIdx.x];
+}
+
+__global__ __launch_bounds__(BPC_BLOCK) void bucket_place_kernel(const int32_t *__restrict__ bucket, int batch, int nb,
+                                                                 const int *__restrict__ blk_cnt, int nblk,
                                                                  int32_t *__restrict__ perm, int4 *__restrict__ items,
                                                                  int *__restrict__ bucket_items, int *__restrict__ counts) {
-    extern __shared__ __align__(16) int bp_cnt[];  // [nb][BP_THREADS]: counts, then write cursors; then [batch] bytes
-    __shared__ int wsum[BP_THREADS / 64];
-    uint8_t *s_b = reinterpret_cast<uint8_t *>(bp_cnt + nb * BP_THREADS);  // the buckets, read once (coalesced)
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int per = (batch + BP_THREADS - 1) / BP_THREADS;
-    const int p_lo = min(batch, t * per), p_hi = min(batch, p_lo + per);
-    for (int p = t; p < batch; p += BP_THREADS) s_b[p] = (uint8_t)min(max(bucket[p], 0), nb - 1);
-    for (int k = 0; k < nb; k++) bp_cnt[k * BP_THREADS + t] = 0;
+    __shared__ int tot[16], before[16], s_start[17], s_istart[17], wcnt[BPC_BLOCK / 64][16];
+    if ((int)threadIdx.x < nb) tot[threadIdx.x] = 0, before[threadIdx.x] = 0;
     __syncthreads();
-    for (int p = p_lo; p < p_hi; p++) bp_cnt[s_b[p] * BP_THREADS + t]++;
-    __syncthreads();
-    // exclusive scan of the flattened (bucket major, thread minor) counts; thread t scans elements [t*nb, (t+1)*nb)
-    int s = 0;
-    for (int k = 0; k < nb; k++) s += bp_cnt[t * nb + k];
-    int incl = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int up = __shfl_up(incl, o);
-        if (lane >= o) incl += up;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int run = incl - s;
-    for (int w2 = 0; w2 < wave; w2++) run += wsum[w2];
-    for (int k = 0; k < nb; k++) {
-        const int v = bp_cnt[t * nb + k];
-        bp_cnt[t * nb + k] = run;
-        run += v;
-    }
-    __syncthreads();
-    // thread 0's cursors are the bucket starts (read before the placement below moves them)
-    __shared__ int s_start[17], s_istart[17];
-    if (t <= nb) s_start[t] = (t < nb) ? bp_cnt[t * BP_THREADS] : batch;
-    __syncthreads();
-    if (t == 0) {
-        int ni = 0;
-        for (int k = 0; k < nb; k++) {
-            s_istart[k] = bucket_items[k] = ni;
-            ni += (s_start[k + 1] - s_start[k] + DX_CH - 1) / DX_CH;
+    for (int i = threadIdx.x; i < nblk * nb; i += BPC_BLOCK) {  // integer sums: order does not matter
+        const int v = blk_cnt[i];
+        if (v) {
+            const int blk = i / nb, k = i - blk * nb;
+            atomicAdd(&tot[k], v);
+            if (blk < (int)blockIdx.x) atomicAdd(&before[k], v);
         }
-        s_istart[nb] = bucket_items[nb] = counts[0] = ni;
+    }
+    const int p = blockIdx.x * BPC_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bk = p < batch ? min(max(bucket[p], 0), nb - 1) : -1;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int rank = 0;
+    for (int k = 0; k < nb; k++) {
+        const unsigned long long m = __ballot(bk == k);
+        if (bk == k) rank = __popcll(m & lt_mask);
+        if (lane == 0) wcnt[wave][k] = __popcll(m);
     }
     __syncthreads();
-    for (int i = t; i < s_istart[nb]; i += BP_THREADS) {
+    if (threadIdx.x == 0) {
+        int a = 0, ni = 0;
+        for (int k = 0; k < nb; k++) {
+            s_start[k] = a, s_istart[k] = ni;
+            a += tot[k], ni += (tot[k] + DX_CH - 1) / DX_CH;
+        }
+        s_start[nb] = a, s_istart[nb] = ni;
+    }
+    __syncthreads();
+    if (p < batch) {
+        int pos = s_start[bk] + before[bk] + rank;
+        for (int w2 = 0; w2 < wave; w2++) pos += wcnt[w2][bk];
+        perm[pos] = p;
+    }
+    if (blockIdx.x != 0) return;
+    if ((int)threadIdx.x <= nb) bucket_items[threadIdx.x] = s_istart[threadIdx.x];
+    if (threadIdx.x == 0) counts[0] = s_istart[nb];
+    for (int i = threadIdx.x; i < s_istart[nb]; i += BPC_BLOCK) {
         int k = 0;
         while (k + 1 < nb && s_istart[k + 1] <= i) k++;
         const int o = s_start[k] + (i - s_istart[k]) * DX_CH;
         items[i] = make_int4(k, o, min(DX_CH, s_start[k + 1] - o), 0);
     }
-    for (int p = p_lo; p < p_hi; p++) perm[bp_cnt[s_b[p] * BP_THREADS + t]++] = p;
 }
 
 // ---- 16 outputs per bucket (the first hidden layer of the multi-layer nets, (16 x buckets) x 1024): f32 MFMA
@@ -1547,6 +1559,7 @@ bool bt_internal_dense_wants_perm(const bt_dense_desc *d) {
            dense_mid_ok(d);
 }
 // layout of the permutation buffer: perm [batch] | items int4[batch / DX_CH + nb] | bucket_items [nb + 1] | counts [4]
+// | block histograms [ceil(batch / BPC_BLOCK)][nb]
 static DensePermTab dense_perm_tab(void *buf, int batch, int nb) {
     DensePermTab t;
     char *p = static_cast<char *>(buf);
@@ -1558,20 +1571,25 @@ static DensePermTab dense_perm_tab(void *buf, int batch, int nb) {
     t.bucket_items = reinterpret_cast<const int *>(p);
     p += bt_align((size_t)(nb + 1) * sizeof(int));
     t.counts = reinterpret_cast<const int *>(p);
+    p += bt_align(4 * sizeof(int));
+    t.blk_cnt = reinterpret_cast<int *>(p);
     return t;
 }
 size_t bt_internal_bucket_perm_bytes(int batch, int nb) {
     return bt_align((size_t)batch * sizeof(int32_t)) + bt_align((size_t)(bt_div_up(batch, DX_CH) + nb) * sizeof(int4)) +
-           bt_align((size_t)(nb + 1) * sizeof(int)) + bt_align(4 * sizeof(int));
+           bt_align((size_t)(nb + 1) * sizeof(int)) + bt_align(4 * sizeof(int)) +
+           bt_align((size_t)bt_div_up(batch, BPC_BLOCK) * nb * sizeof(int));
 }
 int bt_internal_bucket_perm(void *stream, const int32_t *bucket, int batch, int nb, void *buf) {
     BT_REQUIRE(bucket && buf && batch > 0 && batch <= 64 * 1024 && nb > 1 && nb <= 16, "bucket_perm: bad arguments");
-    const size_t lds = (size_t)nb * BP_THREADS * sizeof(int) + bt_align((size_t)batch, 16);
-    if (int rc = dense_set_lds(bucket_perm_kernel, lds)) return rc;
     const DensePermTab t = dense_perm_tab(buf, batch, nb);
-    BT_LAUNCH(BTK_DENSE_FWD, bt_stream(stream), bucket_perm_kernel, dim3(1), dim3(BP_THREADS), lds, bucket, batch, nb,
-              const_cast<int32_t *>(t.perm), const_cast<int4 *>(t.items), const_cast<int *>(t.bucket_items),
-              const_cast<int *>(t.counts));
+    const int nblk = bt_div_up(batch, BPC_BLOCK);
+    BT_LAUNCH(BTK_DENSE_FWD, bt_stream(stream), bucket_count_kernel, dim3(nblk), dim3(BPC_BLOCK), 0, bucket, batch, nb,
+              t.blk_cnt);
+    BT_LAUNCH_CHECK();
+    BT_LAUNCH(BTK_DENSE_FWD, bt_stream(stream), bucket_place_kernel, dim3(nblk), dim3(BPC_BLOCK), 0, bucket, batch, nb,
+              t.blk_cnt, nblk, const_cast<int32_t *>(t.perm), const_cast<int4 *>(t.items),
+              const_cast<int *>(t.bucket_items), const_cast<int *>(t.counts));
     BT_LAUNCH_CHECK();
     return BT_OK;
 }

@@ -17,7 +17,7 @@ KERNELS = ["ft_fwd_lds", "ft_index_kernel", "ft_index_oct_kernel", "ft_bwd_oct",
            "ft_bwd_lds", "ft_bwd_merge", "head_finish_kernel", "dense_fwd_small",
            "dense_bwd_small_light", "dense_bwd_small", "sum_partials_seq4_kernel", "sum_partials4_kernel", "adamw_kernel",
            # the HalfKA multi-layer nets (bench.py --net cfg3 / cfg4)
-           "ft_bwd_lds_any", "ft_bwd_merge_grp", "ft_group_count", "ft_group_scan", "ft_group_place", "bucket_perm_kernel",
+           "ft_bwd_lds_any", "ft_bwd_merge_grp", "ft_group_count", "ft_group_place", "bucket_count_kernel", "bucket_place_kernel", "ft_bwd_merge_step",
            "dense_mfma_fwd", "dense_mfma_dx", "dense_mfma_dw", "dense_mfma_sum", "dense_tail_kernel", "dense_tail_sum",
            "dense_gz_kernel", "factor_expand_kernel", "factor_reduce_kernel"]
 
