@@ -251,17 +251,19 @@ __device__ __forceinline__ float4 bt_act_deriv4(int act, float4 o) {
     case BT_ACT_CRELU:
         return make_float4(pos(o.x) * pos(1.0f - o.x), pos(o.y) * pos(1.0f - o.y), pos(o.z) * pos(1.0f - o.z),
                            pos(o.w) * pos(1.0f - o.w));
+    // (one compare per element: for every finite o the products of dfo.rs with their 0/1 factors come out as below,
+    // signed zeros and the NaN of a negative o included)
     case BT_ACT_SCRELU: {
-        const float hx = (pos(o.x) * pos(1.0f - o.x)) * __builtin_amdgcn_sqrtf(o.x);
-        const float hy = (pos(o.y) * pos(1.0f - o.y)) * __builtin_amdgcn_sqrtf(o.y);
-        const float hz = (pos(o.z) * pos(1.0f - o.z)) * __builtin_amdgcn_sqrtf(o.z);
-        const float hw = (pos(o.w) * pos(1.0f - o.w)) * __builtin_amdgcn_sqrtf(o.w);
-        return make_float4(hx + hx, hy + hy, hz + hz, hw + hw);
+        auto h = [](float v) {
+            const float s = __builtin_amdgcn_sqrtf(v);
+            return !(v >= 1.0f) ? s + s : 0.0f;
+        };
+        return make_float4(h(o.x), h(o.y), h(o.z), h(o.w));
     }
     case BT_ACT_SQRRELU: {
-        const float hx = pos(o.x) * __builtin_amdgcn_sqrtf(o.x), hy = pos(o.y) * __builtin_amdgcn_sqrtf(o.y);
-        const float hz = pos(o.z) * __builtin_amdgcn_sqrtf(o.z), hw = pos(o.w) * __builtin_amdgcn_sqrtf(o.w);
-        return make_float4(hx + hx, hy + hy, hz + hz, hw + hw);
+        const float sx = __builtin_amdgcn_sqrtf(o.x), sy = __builtin_amdgcn_sqrtf(o.y);
+        const float sz = __builtin_amdgcn_sqrtf(o.z), sw = __builtin_amdgcn_sqrtf(o.w);
+        return make_float4(sx + sx, sy + sy, sz + sz, sw + sw);
     }
     default: return make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     }
