@@ -166,7 +166,9 @@ struct bt_ft_step_all {
     bt_ft_fused_adamw base;  // t[0] = table, t[1] = FT bias
     int n_extra;
     bt_adamw_tensor extra[BT_ADAMW_MAX_TENSORS];
-    hipEvent_t done;  // rides on the merge kernel's dispatch packet (may be null)
+    hipEvent_t done = nullptr;  // rides on the merge kernel's dispatch packet (may be null)
+    hipEvent_t wait = nullptr;  // the stream waits for it right before the merge launch: gradients of the extra
+                                // tensors that were formed on another stream (bt_internal_dense_set_side)
 };
 bool bt_internal_ft_step_ok(const bt_ft_desc *d);
 void bt_internal_ft_arm_step(const bt_ft_step_all *step);
@@ -214,6 +216,11 @@ int bt_internal_dense_tail(void *stream, const bt_dense_desc *q1, const bt_dense
 // and (false), and only if bt_internal_dense_takes_gz(desc) says its path forms gz in a kernel of its own
 bool bt_internal_dense_takes_gz(const bt_dense_desc *d);
 void bt_internal_dense_set_gz_ready(bool on);
+// While a side stream is set (calling thread), the kernels of the fused tail and of the sorted MFMA layer whose results
+// only the optimiser needs -- dense_tail_sum, dense_mfma_dw, dense_mfma_sum -- are issued on it, ordered behind the
+// caller's stream through `fork` at the point where their inputs are complete. The caller joins the side stream before
+// it uses the weight / bias gradients or the loss sum. (nullptr, nullptr) switches it off.
+void bt_internal_dense_set_side(void *side_stream, hipEvent_t fork);
 // dense head forward fused with sigmoid-MSE: writes y, grad_y, per-workgroup loss partials and (optionally) gz_out =
 // grad_y * f'(y), the gradient w.r.t. the layer's pre-activation
 int bt_internal_dense_forward_loss(void *stream, const bt_dense_desc *d, const float *w, const float *bias,

@@ -727,6 +727,23 @@ thread_local DensePermTab g_dense_tab;
 // set by net.hip around a bt_dense_backward whose grad_y already is the gradient w.r.t. the layer's pre-activation
 // (the fused tail formed it): the mid-size paths then skip dense_gz_kernel
 thread_local bool g_dense_gy_is_gz = false;
+thread_local hipStream_t g_dense_side = nullptr;  // bt_internal_dense_set_side
+thread_local hipEvent_t g_dense_fork = nullptr;
+thread_local bool g_dense_side_behind = false;  // the side stream already waits for the kernel that produced grad_y
+// Work that only the optimiser waits for goes to the side stream, ordered behind the kernel launched LAST on `s`: the
+// fork event rides on that kernel's dispatch packet (dense_fork_on, before its launch) -- a record of its own on `s`
+// would put a barrier packet between two kernels of the critical path (12 us measured) -- and the side stream waits.
+void dense_fork_on(int kernel_id) {
+    if (g_dense_side) bt_attach_stop_event(kernel_id, g_dense_fork);
+}
+int dense_side_join_fork(hipStream_t s, hipStream_t *out, bool attached) {
+    *out = s;
+    if (!g_dense_side) return BT_OK;
+    if (!attached) BT_HIP(hipEventRecord(g_dense_fork, s));
+    BT_HIP(hipStreamWaitEvent(g_dense_side, g_dense_fork, 0));
+    *out = g_dense_side;
+    return BT_OK;
+}
 constexpr int DX_CH = 64;  // positions per item = 4 waves x one 16-row MFMA tile
 
 // Stable counting sort of the positions by output bucket in two multi-workgroup kernels (the segment grouping of
@@ -1617,15 +1634,24 @@ int bt_internal_dense_tail(void *stream, const bt_dense_desc *q1, const bt_dense
     const size_t lds = ((size_t)n2 * n1 + 2 * n2 + DX_CH * (n1 + 1) + 2 * DX_CH * (n2 + 1) + 2 * DX_CH) * sizeof(float);
     hipStream_t s = bt_stream(stream);
     if (int rc = dense_set_lds(dense_tail_kernel, lds)) return rc;
+    dense_fork_on(BTK_DENSE_BWD_SMALL);
     BT_LAUNCH(BTK_DENSE_BWD_SMALL, s, dense_tail_kernel, dim3(tab.max_items), dim3(TAIL_THREADS), lds, A, tab);
     BT_LAUNCH_CHECK();
-    BT_LAUNCH(BTK_SUM_PARTIALS, s, dense_tail_sum, dim3(bt_div_up(tail_part_floats(n1, n2) - 1, 32), nb + 1), dim3(256), 0,
+    hipStream_t s2;
+    if (int rc = dense_side_join_fork(s, &s2, true)) return rc;
+    g_dense_side_behind = g_dense_side != nullptr;  // ga1 (the next layer's grad_y) is this kernel's
+    BT_LAUNCH(BTK_SUM_PARTIALS, s2, dense_tail_sum, dim3(bt_div_up(tail_part_floats(n1, n2) - 1, 32), nb + 1), dim3(256), 0,
               A.part, n1, n2, nb, dw2, db2, dw3, db3, loss_sum, tab);
     BT_LAUNCH_CHECK();
     return BT_OK;
 }
 
 void bt_internal_dense_set_gz_ready(bool on) { g_dense_gy_is_gz = on; }
+void bt_internal_dense_set_side(void *side_stream, hipEvent_t fork) {
+    g_dense_side = (side_stream && fork) ? bt_stream(side_stream) : nullptr;
+    g_dense_fork = g_dense_side ? fork : nullptr;
+    g_dense_side_behind = false;
+}
 bool bt_internal_dense_takes_gz(const bt_dense_desc *d) {
     return dense_validate(d, "dense_takes_gz") == BT_OK && !dense_bwd_small_ok(d) && (dense_mid_ok(d) || dense_tiny_ok(d));
 }
@@ -1749,16 +1775,23 @@ int bt_dense_backward(void *stream, const bt_dense_desc *d, const float *w, cons
         float *gz = reinterpret_cast<float *>(ws + bt_align((size_t)nrm * rows * d->in * sizeof(float)) +
                                               bt_align((size_t)nrm * rows * sizeof(float)));
         const size_t ngz = (size_t)d->batch * d->out;
+        const bool mfma_path = !tiny && dense_mfma_ok(d) && g_dense_tab.items &&
+                               (size_t)g_dense_tab.max_items * 16 * d->in <= (size_t)nrm * rows * d->in;
+        const bool behind = g_dense_side_behind;
+        g_dense_side_behind = false;
         if (g_dense_gy_is_gz) {
             gz = const_cast<float *>(grad_y);  // (read only below)
         } else {
+            if (mfma_path) dense_fork_on(BTK_DENSE_BWD_DX);
             BT_LAUNCH(BTK_DENSE_BWD_DX, s, dense_gz_kernel, dim3(bt_div_up((long long)ngz, 256)), dim3(256), 0, y, grad_y, gz,
                       ngz, d->act);
             BT_LAUNCH_CHECK();
         }
-        if (!tiny && dense_mfma_ok(d) && g_dense_tab.items &&
-            (size_t)g_dense_tab.max_items * 16 * d->in <= (size_t)nrm * rows * d->in) {
+        if (mfma_path) {
             const DensePermTab tab = g_dense_tab;
+            hipStream_t s2 = s;  // dW and its sum: beside dX (and whatever follows it) when a side stream is set
+            if (g_dense_gy_is_gz && behind) s2 = g_dense_side;  // (the side stream waits for grad_y's kernel already)
+            else if (int rc = dense_side_join_fork(s, &s2, !g_dense_gy_is_gz)) return rc;
             if (grad_x) {
                 BT_LAUNCH(BTK_DENSE_BWD_DX, s, dense_mfma_dx, dim3(tab.max_items), dim3(256), 0, w, gz, grad_x, *d, tab);
                 BT_LAUNCH_CHECK();
@@ -1766,12 +1799,12 @@ int bt_dense_backward(void *stream, const bt_dense_desc *d, const float *w, cons
             const int tw = bt_div_up(d->in / 64, 4);  // 64-column blocks per wave: up to 8 (in <= 2048)
 #define MDW(TW)                                                                                                      \
     case TW:                                                                                                         \
-        BT_LAUNCH(BTK_DENSE_BWD_DW, s, dense_mfma_dw<TW>, dim3(tab.max_items), dim3(256), 0, x, gz, pw, pb, *d, tab);  \
+        BT_LAUNCH(BTK_DENSE_BWD_DW, s2, dense_mfma_dw<TW>, dim3(tab.max_items), dim3(256), 0, x, gz, pw, pb, *d, tab); \
         break;
             switch (tw) { MDW(1) MDW(2) MDW(3) MDW(4) MDW(5) MDW(6) MDW(7) MDW(8) }
 #undef MDW
             BT_LAUNCH_CHECK();
-            BT_LAUNCH(BTK_SUM_PARTIALS, s, dense_mfma_sum, dim3(bt_div_up(16 * d->in + 16, 32), d->buckets), dim3(256), 0,
+            BT_LAUNCH(BTK_SUM_PARTIALS, s2, dense_mfma_sum, dim3(bt_div_up(16 * d->in + 16, 32), d->buckets), dim3(256), 0,
                       pw, pb, dw, dbias, *d, tab);
             BT_LAUNCH_CHECK();
             return BT_OK;

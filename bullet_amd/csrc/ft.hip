@@ -2337,6 +2337,7 @@ int ft_backward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, 
         }
         st.block_start[step->n_extra] = xb;
         const int blocks_w = bt_div_up(n, 256);
+        if (step->wait) BT_HIP(hipStreamWaitEvent(s, step->wait, 0));
         if (step->done) bt_attach_stop_event(BTK_FT_BWD_MERGE, step->done);
         if (p.grouped)
             BT_LAUNCH(BTK_FT_BWD_MERGE, s, ft_bwd_merge_step<true>, dim3(blocks_w + xb), dim3(256), 0, pw, pb, dw, dbias, *d,

@@ -43,6 +43,7 @@ struct bt_net {
     // side stream: the FT sorted index (depends only on the batch indices) is built while the forward runs
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_index = nullptr, ev_fwd = nullptr, ev_head = nullptr, ev_perm = nullptr;
+    hipEvent_t ev_dfork = nullptr, ev_sums = nullptr;  // multi-layer nets: optimiser-only dense kernels on the side stream
     size_t ft_ws_bytes = 0, dense_ws_bytes = 0;
     // bt_net_hint_next_batch: the index structures of the NEXT batch (segment entry lists, bucket permutation, sorted
     // lists) are built on the side stream at the end of the current step, into a second set of buffers
@@ -442,6 +443,8 @@ int bt_net_create(const bt_net_desc *desc, int max_batch, float *ext_params, flo
         hipEventCreateWithFlags(&n->ev_fwd, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&n->ev_head, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&n->ev_perm, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&n->ev_dfork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&n->ev_sums, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&n->ev_next, hipEventDisableTiming) != hipSuccess) {
         bt_set_error("bt_net_create: could not create the side stream / events");
         return fail(BT_ERR_HIP);
@@ -465,6 +468,8 @@ int bt_net_destroy(bt_net *n) {
     if (n->ev_head) (void)hipEventDestroy(n->ev_head);
     if (n->ev_perm) (void)hipEventDestroy(n->ev_perm);
     if (n->ev_next) (void)hipEventDestroy(n->ev_next);
+    if (n->ev_dfork) (void)hipEventDestroy(n->ev_dfork);
+    if (n->ev_sums) (void)hipEventDestroy(n->ev_sums);
     bt_free(n->ft_ws_alt), bt_free(n->perm_alt);
     if (n->side) (void)hipStreamDestroy(n->side);
     delete n;
@@ -582,6 +587,18 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
     if (int rc = forward_impl(n, s, b, fuse_loss && !tail, side_head, head_in_ft && !ready, true, perm.built && !ready,
                               tail ? 1 : -1))
         return rc;
+    // The fused tail's gradient sums and layer 0's weight gradient are needed by the optimiser only: with the tail they
+    // run on the side stream (behind the index build, if one is in flight there), beside dX and the FT backward,
+    // and the compute stream joins them right before the gradient merge (or at the end of this function).
+    struct SideSums {
+        bool on;
+        explicit SideSums(bt_net *n, bool use) : on(use) {
+            if (on) bt_internal_dense_set_side(n->side, n->ev_dfork);
+        }
+        ~SideSums() {
+            if (on) bt_internal_dense_set_side(nullptr, nullptr);
+        }
+    } side_sums(n, tail);
     if (tail) {
         if (int rc = bt_internal_dense_tail(s, &q1, &q_last, n->params + n->t_off[4], n->params + n->t_off[5],
                                             n->params + n->t_off[6], n->params + n->t_off[7], n->a[0], b->targets,
@@ -679,6 +696,10 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
             if (rc) return rc;
         }
     }
+    if (side_sums.on) {
+        bt_internal_dense_set_side(nullptr, nullptr);
+        BT_HIP(hipEventRecord(n->ev_sums, n->side));
+    }
     if (!ready) BT_HIP(hipStreamWaitEvent(s, n->ev_index, 0));  // join
     // bt_net_train_step: AdamW inside the FT gradient merge (table + bias) and, by extra blocks of that launch, for the
     // other tensors, whose gradients are complete by now
@@ -693,9 +714,11 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
         step_all.n_extra = n->n_tensors - 2;
         for (int t = 2; t < n->n_tensors; t++) step_all.extra[t - 2] = n->adam[t];
         step_all.done = opt->done;
+        step_all.wait = side_sums.on ? n->ev_sums : nullptr;
         bt_internal_ft_arm_step(&step_all);
         opt->stepped = true;
     }
+    const bool join_late = side_sums.on && !(opt && opt->stepped);  // (armed: the merge launch waits for ev_sums itself)
     if (fuse_ft) {
         if (int rc = bt_internal_ft_backward_fused(s, &f, n->gz0, n->params + n->t_off[2],
                                                    n->d.dense_bucketed[0] ? b->buckets : nullptr, q0.buckets, n->hid,
@@ -706,6 +729,7 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
                                                 n->grads + n->t_off[1], n->ft_ws, n->ft_ws_bytes))
         return rc;
     if (int rc = factor_reduce()) return rc;
+    if (join_late) BT_HIP(hipStreamWaitEvent(s, n->ev_sums, 0));  // every gradient and the loss sum are complete on `s`
     return prepare_next(n);
 }
 }  // namespace
