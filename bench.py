@@ -250,7 +250,7 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
     adj = torch.tensor([parallel.adj_factor(global_batch)], device="cuda")
     lr = torch.tensor([1e-3], device="cuda")
     torch.cuda.synchronize()  # parameters, adj, lr: written on torch's stream
-    multi_layer = net_name != "cfg2" and not args.no_hints
+    hints = not args.no_hints
     nbytes = words * 4
 
     def upload(k, dst, on):
@@ -286,7 +286,8 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
                     L.bt_event_sync(consumed[nxt])
             upload((i + 1) % n_distinct, nxt, copy)
             L.bt_event_record(uploaded[nxt], copy)
-        if multi_layer:  # its index structures are built during this step, once the upload has landed
+        if hints:  # multi-layer nets: its index structures are built during this step, once the upload has landed;
+            # the single-layer net: the next step's index build is ordered behind this step without a fork packet
             net.hint_next(dev_batches[nxt], uploaded[nxt] if args.upload != "none" else None)
         if args.upload != "none":
             L.bt_event_query(uploaded[cur], C.byref(landed))
@@ -406,8 +407,9 @@ def main():
                     help="milliseconds of forward-only passes before the warm-up steps (GPU clock ramp; no training state "
                          "is touched)")
     ap.add_argument("--no-hints", action="store_true",
-                    help="multi-layer nets: do not announce the next batch (bt_net_hint_next_batch), so its index "
-                         "structures are built on the step's own critical path")
+                    help="do not announce the next batch (bt_net_hint_next_batch): multi-layer nets then build its index "
+                         "structures on the step's own critical path, the single-layer net forks its side stream "
+                         "with an event packet per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-subrecords", action="store_true",
                     help="only the main workload: no fixture_occupancy / halfka (N = 1) or weak (N > 1) sub-records")

@@ -50,6 +50,11 @@ struct bt_net {
     void *ft_ws_alt = nullptr, *perm_alt = nullptr;
     bt_batch next = {}, prep_key = {};
     bool has_next = false, prepared = false;
+    // single-layer fused path: the side stream was ordered behind the previous step (its last kernel's completion
+    // event) and the hinted batch's ready event when that step ended, so this step needs no fork packet on `s`
+    bool primed = false;
+    bt_batch primed_key = {};
+    hipEvent_t ev_step = nullptr;
     hipEvent_t next_ready = nullptr, ev_next = nullptr;
 };
 
@@ -230,8 +235,10 @@ struct PermScope {
 // before it forks the side stream); otherwise they are built here, in stream order
 // perm_on_side: the bucket-order permutation is being built on the side stream (ev_perm): joined before the layers
 // n_layers: dense layers to run (the fused tail of bt_net_forward_backward takes over after the first)
+// fwd_event: record ev_fwd when the forward pass is complete (the side-stream head backward waits for it)
 int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bool want_gz0 = false,
-                 bool head_in_ft = false, bool groups_ready = false, bool perm_on_side = false, int n_layers = -1) {
+                 bool head_in_ft = false, bool groups_ready = false, bool perm_on_side = false, int n_layers = -1,
+                 bool fwd_event = true) {
     bt_ft_desc f = ft_desc(n, b->batch);
     const int32_t *idx[2] = {b->stm, b->nstm};
     const float *w0 = nullptr;
@@ -249,14 +256,15 @@ int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bo
             return rc;
         // Cross-stream packets cost a few us of bubble each on this stream. The index join goes here, between the FT
         // forward and the finishing kernel (it has long been satisfied), and "forward done" (ev_fwd) rides on the
-        // finishing kernel's own dispatch packet instead of a separate hipEventRecord.
+        // finishing kernel's own dispatch packet instead of a separate hipEventRecord -- when somebody waits for it:
+        // a completion signal on a packet delays the next kernel of the stream by 4-5 us too.
         BT_HIP(hipStreamWaitEvent(s, n->ev_index, 0));
-        bt_attach_stop_event(BTK_DENSE_FWD_SMALL, n->ev_fwd);
+        if (fwd_event) bt_attach_stop_event(BTK_DENSE_FWD_SMALL, n->ev_fwd);
         const int rc = bt_internal_head_finish(s, &q, n->zpart, bt_internal_ft_head_parts(&f), n->params + n->t_off[3], bk,
                                                b->targets, n->d.use_entry_weights ? b->entry_weights : nullptr, n->a[0],
                                                n->grad_y, want_gz0 ? n->gz0 : nullptr, n->loss_partials,
                                                &n->n_loss_partials, want_gz0 ? n->gz_parts : nullptr);
-        if (rc) (void)bt_take_stop_event(BTK_DENSE_FWD_SMALL);  // not launched: do not leave the event armed
+        if (rc && fwd_event) (void)bt_take_stop_event(BTK_DENSE_FWD_SMALL);  // not launched: do not leave the event armed
         return rc;
     }
     if (int rc = bt_ft_forward_prebuilt(s, &f, w0, n->params + n->t_off[1], idx, n->hid, n->saved, n->ft_ws,
@@ -301,14 +309,15 @@ int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bo
 
 // end of a step: build the hinted batch's index structures on the side stream into the second buffer set. The side
 // stream is ordered behind ev_fork, i.e. behind everything queued on the compute stream before this step, which
-// includes the last readers of that buffer set (the step before this one).
-int prepare_next(bt_net *n) {
+// includes the last readers of that buffer set (the step before this one) -- or it is behind a kernel of this step
+// already (side_behind: the fused tail's fork), and no ev_fork was recorded.
+int prepare_next(bt_net *n, bool side_behind) {
     if (!n->has_next) return BT_OK;
     n->has_next = false;
     const bt_batch *b = &n->next;
     bt_ft_desc f = ft_desc(n, b->batch);
     const int32_t *idx[2] = {b->stm, b->nstm};
-    BT_HIP(hipStreamWaitEvent(n->side, n->ev_fork, 0));
+    if (!side_behind) BT_HIP(hipStreamWaitEvent(n->side, n->ev_fork, 0));
     if (n->next_ready) BT_HIP(hipStreamWaitEvent(n->side, n->next_ready, 0));
     if (int rc = bt_internal_ft_build_groups(n->side, &f, idx, n->ft_ws_alt, n->ft_ws_bytes)) return rc;
     if (n->perm_alt && PermScope::perm_usable(n, b))
@@ -445,6 +454,7 @@ int bt_net_create(const bt_net_desc *desc, int max_batch, float *ext_params, flo
         hipEventCreateWithFlags(&n->ev_perm, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&n->ev_dfork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&n->ev_sums, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&n->ev_step, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&n->ev_next, hipEventDisableTiming) != hipSuccess) {
         bt_set_error("bt_net_create: could not create the side stream / events");
         return fail(BT_ERR_HIP);
@@ -470,6 +480,7 @@ int bt_net_destroy(bt_net *n) {
     if (n->ev_next) (void)hipEventDestroy(n->ev_next);
     if (n->ev_dfork) (void)hipEventDestroy(n->ev_dfork);
     if (n->ev_sums) (void)hipEventDestroy(n->ev_sums);
+    if (n->ev_step) (void)hipEventDestroy(n->ev_step);
     bt_free(n->ft_ws_alt), bt_free(n->perm_alt);
     if (n->side) (void)hipStreamDestroy(n->side);
     delete n;
@@ -547,15 +558,19 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
     n->prepared = false;
     if (ready) {
         std::swap(n->ft_ws, n->ft_ws_alt), std::swap(n->perm, n->perm_alt);
-        BT_HIP(hipEventRecord(n->ev_fork, s));
-        BT_HIP(hipStreamWaitEvent(s, n->ev_next, 0));
+        BT_HIP(hipStreamWaitEvent(s, n->ev_next, 0));  // (ev_fork for prepare_next: below, unless the tail forks anyway)
     } else {
         // segment-grouped tables: the entry lists are needed by the forward pass too, so they are built on `s` first
         if (int rc = bt_internal_ft_build_groups(s, &f, idx, n->ft_ws, n->ft_ws_bytes)) return rc;
         // fork: sorted index build on the side stream, ordered after everything already queued on `s`
-        BT_HIP(hipEventRecord(n->ev_fork, s));
-        BT_HIP(hipStreamWaitEvent(n->side, n->ev_fork, 0));
+        const bool primed = n->primed && n->primed_key.batch == b->batch && n->primed_key.stm == b->stm &&
+                            n->primed_key.nstm == b->nstm && n->primed_key.buckets == b->buckets;
+        if (!primed) {
+            BT_HIP(hipEventRecord(n->ev_fork, s));
+            BT_HIP(hipStreamWaitEvent(n->side, n->ev_fork, 0));
+        }
     }
+    n->primed = false;
     PermScope perm(n, n->side, b, !ready);  // (multi-layer bucketed nets) needed after the FT forward: side stream first
     if (perm.rc) return perm.rc;
     if (!ready) {
@@ -584,8 +599,13 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
     // the tail can hand layer 0 the gradient w.r.t. its pre-activation directly (one multiply more in the tail kernel,
     // one elementwise kernel less on the critical path)
     const bool tail_gz = tail && !bt_internal_dense_head_ok(&q0) && bt_internal_dense_takes_gz(&q0);
+    // Every packet on `s` costs a bubble of ~5 us: with the fused tail the side stream is put behind the tail kernel of
+    // this step (SideSums below), which orders prepare_next behind the previous step as well.
+    if (ready && !tail) BT_HIP(hipEventRecord(n->ev_fork, s));
+    // (the head's gradients come out of the FT backward and its merge: nothing runs beside them, nobody needs ev_fwd)
+    const bool head_grads_in_ft = side_head && head_in_ft && bt_internal_ft_fused_head_grad_ok(&f, q0.buckets);
     if (int rc = forward_impl(n, s, b, fuse_loss && !tail, side_head, head_in_ft && !ready, true, perm.built && !ready,
-                              tail ? 1 : -1))
+                              tail ? 1 : -1, !head_grads_in_ft))
         return rc;
     // The fused tail's gradient sums and layer 0's weight gradient are needed by the optimiser only: with the tail they
     // run on the side stream (behind the index build, if one is in flight there), beside dX and the FT backward,
@@ -622,10 +642,11 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
         BT_LAUNCH_CHECK();
         return BT_OK;
     };
-    if (side_head && head_in_ft && bt_internal_ft_fused_head_grad_ok(&f, q0.buckets)) {
+    if (head_grads_in_ft) {
         // The FT backward forms the head's weight gradient from the activation tile it stages anyway (matrix cores,
         // beside its LDS-bound reduction), and its merge kernel adds up the head's bias gradient and the loss from
         // the finishing kernel's partials: no second stream, no second pass over the [B][2H] activations.
+        const bool hinted = n->has_next;
         n->has_next = false;
         bt_ft_head_grads hg{n->grads + n->t_off[2], n->grads + n->t_off[3], n->gz_parts, n->loss_partials,
                             n->n_loss_partials, loss_sum_dev};
@@ -635,11 +656,20 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
             fa.adj = opt->adj, fa.lr = opt->lr;
             hg.step = &fa, hg.done = opt->done, opt->stepped = true;
         }
+        // A hinted next batch: its index build (side stream, next step) has to wait for this step's last reader of the
+        // index workspace and for the batch itself. Both waits are queued on the side stream now -- the first on the
+        // completion event that rides on the merge kernel's packet -- and the next step forks without a packet on `s`.
+        if (hinted && !hg.done) hg.done = n->ev_step;
         if (int rc = bt_internal_ft_backward_fused(s, &f, n->gz0, n->params + n->t_off[2],
                                                    n->d.dense_bucketed[0] ? b->buckets : nullptr, q0.buckets, n->hid,
                                                    n->saved, n->grads + n->t_off[0], n->grads + n->t_off[1], n->ft_ws,
                                                    n->ft_ws_bytes, &hg))
             return rc;
+        if (hinted) {
+            BT_HIP(hipStreamWaitEvent(n->side, hg.done, 0));
+            if (n->next_ready) BT_HIP(hipStreamWaitEvent(n->side, n->next_ready, 0));
+            n->primed = true, n->primed_key = n->next;
+        }
         return factor_reduce();
     }
     if (side_head) {
@@ -730,7 +760,7 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
         return rc;
     if (int rc = factor_reduce()) return rc;
     if (join_late) BT_HIP(hipStreamWaitEvent(s, n->ev_sums, 0));  // every gradient and the loss sum are complete on `s`
-    return prepare_next(n);
+    return prepare_next(n, ready && tail);
 }
 }  // namespace
 
