@@ -130,8 +130,9 @@ int bt_internal_ft_forward_head(void *stream, const bt_ft_desc *d, const float *
                                 size_t workspace_bytes);
 // the two halves of bt_ft_build_index: segment entry lists (needed by the forward of a segment-grouped table; no-op
 // otherwise) and the per-chunk sorted lists (backward only); bt_internal_ft_grouped: does the plan use the lists?
+// (done: optional completion event that rides on the last kernel's dispatch packet; grouped tables only)
 int bt_internal_ft_build_groups(void *stream, const bt_ft_desc *d, const int32_t *const *idx, void *workspace,
-                                size_t workspace_bytes);
+                                size_t workspace_bytes, hipEvent_t done = nullptr);
 int bt_internal_ft_build_sorted(void *stream, const bt_ft_desc *d, const int32_t *const *idx, void *workspace,
                                 size_t workspace_bytes);
 bool bt_internal_ft_grouped(const bt_ft_desc *d);

@@ -2502,7 +2502,7 @@ int bt_internal_ft_forward_head(void *stream, const bt_ft_desc *d, const float *
 // ---- internal: the two halves of bt_ft_build_index. The entry lists (segment-grouped tables only) are needed by
 // the forward pass, the per-chunk sorted lists only by the backward pass, so net.hip puts them on different streams.
 int bt_internal_ft_build_groups(void *stream, const bt_ft_desc *d, const int32_t *const *idx, void *workspace,
-                                size_t workspace_bytes) {
+                                size_t workspace_bytes, hipEvent_t done) {
     if (int rc = ft_validate(d, "bt_ft_build_index")) return rc;
     BT_REQUIRE(idx && idx[0] && workspace, "bt_ft_build_index: null pointer");
     BT_REQUIRE(d->n_inputs == 1 || idx[1], "bt_ft_build_index: null index pointer for input 1");
@@ -2519,6 +2519,7 @@ int bt_internal_ft_build_groups(void *stream, const bt_ft_desc *d, const int32_t
     BT_LAUNCH(BTK_FT_INDEX, s, ft_group_count, dim3(p.grp_blocks), dim3(GRP_BLOCK), 0, i0, i1, d->batch, d->nnz, d->cols,
               p.tc, p.nseg, E, seg_of, blk);
     BT_LAUNCH_CHECK();
+    if (done) bt_attach_stop_event(BTK_FT_INDEX, done);
     BT_LAUNCH(BTK_FT_INDEX, s, ft_group_place, dim3(p.grp_blocks), dim3(GRP_BLOCK), 0, seg_of, blk, p.grp_blocks, p.nseg, E,
               p.fwd_item, p.g_ch, reinterpret_cast<int *>(ws + p.off_elist), reinterpret_cast<int4 *>(ws + p.off_chunks),
               reinterpret_cast<int4 *>(ws + p.off_fitems), reinterpret_cast<int4 *>(ws + p.off_bitems),

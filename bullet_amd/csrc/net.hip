@@ -42,7 +42,7 @@ struct bt_net {
     void *ft_ws = nullptr, *dense_ws = nullptr;
     // side stream: the FT sorted index (depends only on the batch indices) is built while the forward runs
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_index = nullptr, ev_fwd = nullptr, ev_head = nullptr, ev_perm = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_index = nullptr, ev_fwd = nullptr, ev_head = nullptr;
     hipEvent_t ev_dfork = nullptr, ev_sums = nullptr;  // multi-layer nets: optimiser-only dense kernels on the side stream
     size_t ft_ws_bytes = 0, dense_ws_bytes = 0;
     // bt_net_hint_next_batch: the index structures of the NEXT batch (segment entry lists, bucket permutation, sorted
@@ -233,7 +233,9 @@ struct PermScope {
 
 // groups_ready: the segment entry lists of this batch are already in ft_ws (bt_net_forward_backward builds them
 // before it forks the side stream); otherwise they are built here, in stream order
-// perm_on_side: the bucket-order permutation is being built on the side stream (ev_perm): joined before the layers
+// perm_on_side: the bucket-order permutation is being built on the side stream, in front of the sorted index: the
+// side stream is joined before the layers, once for both (ev_index; the index build ends before the FT forward does,
+// and a second wait packet before the FT backward would cost another bubble on `s`)
 // n_layers: dense layers to run (the fused tail of bt_net_forward_backward takes over after the first)
 // fwd_event: record ev_fwd when the forward pass is complete (the side-stream head backward waits for it)
 int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bool want_gz0 = false,
@@ -271,7 +273,7 @@ int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bo
                                         n->ft_ws_bytes))
         return rc;
     const float *x = n->hid;
-    if (perm_on_side) BT_HIP(hipStreamWaitEvent(s, n->ev_perm, 0));
+    if (perm_on_side) BT_HIP(hipStreamWaitEvent(s, n->ev_index, 0));
     if (n_layers < 0) n_layers = n->d.n_dense;
     for (int k = 0; k < n_layers; k++) {
         bt_dense_desc q = dn_desc(n, k, b->batch);
@@ -451,7 +453,6 @@ int bt_net_create(const bt_net_desc *desc, int max_batch, float *ext_params, flo
         hipEventCreateWithFlags(&n->ev_index, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&n->ev_fwd, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&n->ev_head, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&n->ev_perm, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&n->ev_dfork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&n->ev_sums, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&n->ev_step, hipEventDisableTiming) != hipSuccess ||
@@ -476,7 +477,6 @@ int bt_net_destroy(bt_net *n) {
     if (n->ev_index) (void)hipEventDestroy(n->ev_index);
     if (n->ev_fwd) (void)hipEventDestroy(n->ev_fwd);
     if (n->ev_head) (void)hipEventDestroy(n->ev_head);
-    if (n->ev_perm) (void)hipEventDestroy(n->ev_perm);
     if (n->ev_next) (void)hipEventDestroy(n->ev_next);
     if (n->ev_dfork) (void)hipEventDestroy(n->ev_dfork);
     if (n->ev_sums) (void)hipEventDestroy(n->ev_sums);
@@ -561,12 +561,15 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
         BT_HIP(hipStreamWaitEvent(s, n->ev_next, 0));  // (ev_fork for prepare_next: below, unless the tail forks anyway)
     } else {
         // segment-grouped tables: the entry lists are needed by the forward pass too, so they are built on `s` first
-        if (int rc = bt_internal_ft_build_groups(s, &f, idx, n->ft_ws, n->ft_ws_bytes)) return rc;
-        // fork: sorted index build on the side stream, ordered after everything already queued on `s`
+        // fork: sorted index build on the side stream, ordered after everything already queued on `s` (grouped tables:
+        // the fork event rides on the entry lists' last kernel instead of a packet of its own)
         const bool primed = n->primed && n->primed_key.batch == b->batch && n->primed_key.stm == b->stm &&
                             n->primed_key.nstm == b->nstm && n->primed_key.buckets == b->buckets;
+        const bool ride = !primed && bt_internal_ft_grouped(&f);
+        if (int rc = bt_internal_ft_build_groups(s, &f, idx, n->ft_ws, n->ft_ws_bytes, ride ? n->ev_fork : nullptr))
+            return rc;
         if (!primed) {
-            BT_HIP(hipEventRecord(n->ev_fork, s));
+            if (!ride) BT_HIP(hipEventRecord(n->ev_fork, s));
             BT_HIP(hipStreamWaitEvent(n->side, n->ev_fork, 0));
         }
     }
@@ -574,7 +577,6 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
     PermScope perm(n, n->side, b, !ready);  // (multi-layer bucketed nets) needed after the FT forward: side stream first
     if (perm.rc) return perm.rc;
     if (!ready) {
-        if (perm.built) BT_HIP(hipEventRecord(n->ev_perm, n->side));
         if (int rc = bt_internal_ft_build_sorted(n->side, &f, idx, n->ft_ws, n->ft_ws_bytes)) return rc;
         BT_HIP(hipEventRecord(n->ev_index, n->side));
     }
@@ -730,7 +732,7 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
         bt_internal_dense_set_side(nullptr, nullptr);
         BT_HIP(hipEventRecord(n->ev_sums, n->side));
     }
-    if (!ready) BT_HIP(hipStreamWaitEvent(s, n->ev_index, 0));  // join
+    if (!ready && !perm.built) BT_HIP(hipStreamWaitEvent(s, n->ev_index, 0));  // join (perm.built: joined before the layers)
     // bt_net_train_step: AdamW inside the FT gradient merge (table + bias) and, by extra blocks of that launch, for the
     // other tensors, whose gradients are complete by now
     bt_ft_step_all step_all;
