@@ -370,6 +370,37 @@ def test_next_batch_hint_changes_nothing(name):
         assert losses == runs[0][0] and torch.equal(params, runs[0][1])
 
 
+@pytest.mark.parametrize("name", ["cfg3_multilayer_segment", "cfg2_buckets", "l1_in1024_mfma_tail"])
+def test_hinted_train_steps_queued_without_host_syncs(name):
+    """The cross-stream ordering of a hinted run when the host never waits: twelve bt_net_train_step calls over three
+    alternating batches are queued back to back (next batch hinted, side stream primed at the end of the step before /
+    fused-tail kernels on the side stream) and must leave the same bits as the same steps with a host sync after
+    each and no hints."""
+    cfg, (kind, layout, fact), nb, ft_eff = NETS[name]
+    batches = fixture_batches(kind, layout, fact, nb, 0.75, 3, batch=4096)
+    if cfg.get("use_entry_weights"):
+        batches = [(s, n, b, t, np.full(t.shape[0], 0.75, np.float32)) for s, n, b, t, _ in batches]
+    dev_b = [[gu.dev(a) for a in bt] for bt in batches]
+    runs = []
+    for hinted in (False, True, True):
+        net = lib.Net(lib.make_net_desc(**cfg), 4096)
+        net.init_weights(seed=11, ft_effective_inputs=ft_eff)
+        tbs = [net.make_batch(*t) for t in dev_b]
+        adj, lrd = torch.tensor([1.0 / 4096], device="cuda"), torch.tensor([0.001], device="cuda")
+        torch.cuda.synchronize()
+        for i in range(12):
+            if hinted:
+                net.hint_next(tbs[(i + 1) % 3])
+            net.train_step(tbs[i % 3], adj, lrd)
+            if not hinted:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        runs.append((net.loss.item(), net.params.clone()))
+        net.close()
+    for loss, params in runs[1:]:
+        assert loss == runs[0][0] and torch.equal(params, runs[0][1])
+
+
 @pytest.mark.parametrize("hidden", [1024, 1536])
 def test_full_size_config3_config4_properties(hidden):
     """BASELINE configs[2] (H = 1024) and configs[3] (H = 1536: the per-GPU net of the data-parallel config,
