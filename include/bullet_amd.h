@@ -332,8 +332,11 @@ int bt_net_forward_backward(bt_net *net, void *stream, const bt_batch *batch, fl
  * (same net, its tensors complete in `stream` order by now, or once `ready_event` -- a hipEvent_t, may be NULL -- has
  * fired). Multi-layer / king-bucketed nets then build next's index structures (entry lists, bucket order, sorted
  * lists: they depend on the indices only) on their side stream while the current step runs, in a second buffer
- * set, and the following bt_net_forward_backward(next) starts with them in place. Results are identical with or
- * without the hint; a hint that does not match the following call is ignored. No counterpart in the reference. */
+ * set, and the following bt_net_forward_backward(next) starts with them in place. The single-layer bucketed net keeps
+ * building the index beside its forward pass, but puts its side stream behind the current step and `ready_event` when
+ * the current step ends, so the following step forks without an event packet on `stream` (~5 us). Results are
+ * identical with or without the hint; a hint that does not match the following call is ignored. No counterpart in the
+ * reference. */
 int bt_net_hint_next_batch(bt_net *net, const bt_batch *next, void *ready_event);
 /* AdamW on every tensor with g = adj * grad (adj = 1/global_batch), adam.rs:121-131 */
 int bt_net_optimiser_step(bt_net *net, void *stream, const float *adj_dev, const float *lr_dev);
