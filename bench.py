@@ -148,13 +148,14 @@ def roofline_record(dom, c, ms, sample, steps, B, nbar, netcfg, step_s, traffic_
     per_launch = abytes / launches_per_step
     ach = per_launch / avg_s / 1e9
     entry = next((v for k, v in traffic_tab.items() if isinstance(v, dict) and v.get("bench_id", k) == dom), None)
+    kernel_name = (entry or {}).get("kernel", dom)  # the kernel's real name (the live table files it under `dom`)
     measured_batch = (traffic_tab.get("_step") or {}).get("batch", 16384)  # the counters were collected at this batch
     if B != measured_batch:
         entry, traffic_tab = None, {}
     traffic = entry.get("hbm_bytes_per_launch") if entry else None
     lds = dom in ("ft_fwd_lds", "ft_bwd_lds")
     peak = LDS_PEAK_GBS if lds else HBM_PEAK_GBS
-    rec = {"kernel": (entry or {}).get("kernel", dom), "bound": "lds" if lds else "hbm", "achieved": ach, "peak": peak,
+    rec = {"kernel": kernel_name, "bound": "lds" if lds else "hbm", "achieved": ach, "peak": peak,
            "unit": "GB/s", "frac": ach / peak, "traffic": traffic,
            "hbm_frac": (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
            "algorithmic_vs_hbm": ach / HBM_PEAK_GBS,
