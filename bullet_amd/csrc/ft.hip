@@ -1752,17 +1752,32 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
             const int tt = min(t, max(n - 4, 0));
             x0 = sp[(tt + 0) * 8], x1 = sp[(tt + 1) * 8], x2 = sp[(tt + 2) * 8], x3 = sp[(tt + 3) * 8];
         };
+        // The four waves of a SIMD issue oldest-first: with equal work the low wave ids run ahead and the last ones
+        // finish the chunk alone, the LDS half idle, while the others wait at the barrier. Rotating the issue priority
+        // every two rows keeps the four level (-3 us; every four rows: -2.5, every eight: worse at low occupancy).
+        const int wq = wv >> 2;  // position among the four waves of this SIMD
+        auto prio = [&](int k) {
+            if constexpr (GRP) return;  // (segment-grouped tables: other kernels share the CUs then, and it costs 1-2 %)
+            switch ((k + wq) & 3) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+            }
+        };
+#define ROWS4(S, A, B, C, D) prio(2 * (S)), row(A), row(B), prio(2 * (S) + 1), row(C), row(D)
         // peeled: sets 0 and 1 were fetched before the staging loads of the next chunk
-        if (0 < n) row(qa0), row(qa1), row(qa2), row(qa3);
+        if (0 < n) ROWS4(0, qa0, qa1, qa2, qa3);
         fetch(8, qa0, qa1, qa2, qa3);
-        if (4 < n) row(qb0), row(qb1), row(qb2), row(qb3);
+        if (4 < n) ROWS4(1, qb0, qb1, qb2, qb3);
         fetch(12, qb0, qb1, qb2, qb3);
         for (int t = 8; t < n; t += 8) {
-            row(qa0), row(qa1), row(qa2), row(qa3);
+            ROWS4(t >> 2, qa0, qa1, qa2, qa3);
             fetch(t + 8, qa0, qa1, qa2, qa3);
-            if (t + 4 < n) row(qb0), row(qb1), row(qb2), row(qb3);
+            if (t + 4 < n) ROWS4((t >> 2) + 1, qb0, qb1, qb2, qb3);
             fetch(t + 12, qb0, qb1, qb2, qb3);
         }
+#undef ROWS4
     }
     __syncthreads();
     fixup(cur_fix, cur_nfix);
