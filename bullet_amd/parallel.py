@@ -66,12 +66,20 @@ class Comm:
         L = lib.load()
         rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
         ident = C.create_string_buffer(128)
+        payload, err = None, None
         if rank == 0:
-            lib.check(L.bt_comm_unique_id(ident))
+            try:
+                lib.check(L.bt_comm_unique_id(ident))
+                payload = ident.raw
+            except Exception as e:  # the other ranks are waiting in the broadcast: tell them, then raise everywhere
+                err = e
         if world > 1:
-            box = [ident.raw]
+            box = [payload]
             dist.broadcast_object_list(box, src=0)
-            ident = C.create_string_buffer(box[0], 128)
+            payload = box[0]
+        if payload is None:
+            raise err or RuntimeError("rank 0 could not create the RCCL unique id")
+        ident = C.create_string_buffer(payload, 128)
         h = C.c_void_p()
         lib.check(L.bt_comm_init_rank(ident, rank, world, C.byref(h)))
         return cls(h, rank, world)
