@@ -338,7 +338,7 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
     cand = {k: v for k, v in warm.items() if k.startswith("ft_") and k != "ft_index_kernel"} or \
            {k: v for k, v in warm.items() if k != "ft_index_kernel"}
     dom = max(cand, key=lambda k: cand[k][1]) if cand else None
-    SAMPLE = 8 if steps >= 64 else 4  # (a short run still gets a handful of timed launches)
+    SAMPLE = 8 if steps >= 64 else max(1, -(-steps // 3))  # (a short run gets three timed launches: each costs ~10 us)
     if comm is not None:
         comm.barrier(stream)
     if profile and dom:
