@@ -447,7 +447,8 @@ __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t 
 // (pairs of a run in ascending entry order, parts in order), so the result does not depend on where a run lands.
 constexpr int OCT_SLOTS = 64;                    // part slots per chunk (LDS: 64 x 128 B)
 constexpr int OCT_FIX = OCT_SLOTS / 2;           // cut features per chunk (each has >= 2 parts)
-constexpr int OCT_WAVES = 16;                    // waves of the backward workgroup
+constexpr int OCT_WAVES = 12;                    // waves of the backward workgroup that reduce (one stream of rows each)
+constexpr int OCT_STAGERS = 4;                   // its other waves form the staged gradient tile (one per SIMD)
 constexpr int OCT_IDX_THREADS = 512;
 constexpr int OCT_META_BYTES = 64 + OCT_FIX * 8; // u16 wave_start[17], n_fix | uint2 fix[OCT_FIX]
 constexpr uint32_t OCT_PAD2 = ((uint32_t)(FT_CHUNK << 7) << 16) | (uint32_t)(FT_CHUNK << 7);
@@ -462,8 +463,8 @@ __host__ __device__ inline size_t oct_index_lds_bytes(int tc) {
            ((size_t)((tc + 1) & ~1) + 3 * IC + IC / 8 + (size_t)(IC / 64 + 1) * 64) * 2;
 }
 __device__ __forceinline__ int oct_wave_of(int o) {  // serpentine deal of octet o (sorted by length) to the waves
-    const int r = o >> 4, i = o & 15;
-    return (r & 1) ? 15 - i : i;
+    const int r = o / OCT_WAVES, i = o % OCT_WAVES;
+    return (r & 1) ? OCT_WAVES - 1 - i : i;
 }
 
 // (min. 6 waves per SIMD = at most 80 VGPRs: a workgroup of this kernel then fits beside a resident FT-forward
@@ -676,8 +677,8 @@ __global__ __launch_bounds__(OCT_IDX_THREADS, 6) void ft_index_oct_kernel(const 
     if (wave == 0) {
         uint32_t rows = 0;
         if (lane < OCT_WAVES)
-            for (int r = 0; r * 16 < n_oct; r++) {
-                const int o = r * 16 + ((r & 1) ? 15 - lane : lane);
+            for (int r = 0; r * OCT_WAVES < n_oct; r++) {
+                const int o = r * OCT_WAVES + ((r & 1) ? OCT_WAVES - 1 - lane : lane);
                 if (o < n_oct) octrow[o] = (uint16_t)rows, rows += omax[o];
             }
         rows = (rows + 3) & ~3u;
@@ -848,6 +849,16 @@ __device__ __forceinline__ float row_ror8(float v) {  // the value of lane ^ 8 (
 template <int N>
 __device__ __forceinline__ int row_share(int v) {  // broadcast lane N of each 16-lane row (DPP, no LDS traffic)
     return __builtin_amdgcn_update_dpp(v, v, 0x150 + N, 0xF, 0xF, true);
+}
+
+// The word held by slot J of the lane's own 8-lane group (fwd_gather_slot's map: a 16-lane row holds one group on lanes
+// 0-3 and 12-15 and one on lanes 4-11): two DPP row_share moves, each writing its group's two banks.
+template <int J>
+__device__ __forceinline__ uint32_t oct_group_bcast(uint32_t v) {
+    constexpr int LA = J < 4 ? J : 8 + J, LB = 4 + J;
+    int t = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x150 + LA, 0xF, 0x9, false);
+    t = __builtin_amdgcn_update_dpp(t, (int)v, 0x150 + LB, 0xF, 0x6, false);
+    return (uint32_t)t;
 }
 
 __device__ __forceinline__ int tile_row(bool pair, int rt, int half_rows, int local4) {
@@ -1523,11 +1534,41 @@ typedef float oct_f32x4 __attribute__((ext_vector_type(4)));
 // loop wait for the loads fetched ahead for the NEXT chunk (stream rows, staging data) -- the latency those
 // prefetches exist to hide. Nothing in this kernel hands global data from one wave to another.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Developer build only (-DBT_STAMPS, tools/stamps_bwd.sh): shader-clock stamps at the phase boundaries of the octet
+// backward's chunk loop, one per wave of the first BT_STAMP_WGS workgroups, into a buffer nothing else reads.
+#ifdef BT_STAMPS
+constexpr int BT_STAMP_WGS = 8, BT_STAMP_CHUNKS = 20, BT_STAMP_N = 8;
+__device__ unsigned long long bt_stamps[BT_STAMP_WGS][16][BT_STAMP_CHUNKS][BT_STAMP_N];
+#define BT_STAMPC(i, ch)                                                                                  \
+    do {                                                                                                  \
+        if (blockIdx.x < BT_STAMP_WGS && (threadIdx.x & 63) == 0 && (ch) - c_lo < BT_STAMP_CHUNKS)        \
+            bt_stamps[blockIdx.x][wv][(ch) - c_lo][i] = __builtin_amdgcn_s_memtime();                     \
+    } while (0)
+#define BT_STAMP(i) BT_STAMPC(i, c)
+#ifndef BT_STAMP7_POS
+#define BT_STAMP7_POS 3
+#endif
+#define BT_STAMP7(pos, ch)      \
+    do {                        \
+        if (BT_STAMP7_POS == pos) BT_STAMPC(7, ch); \
+    } while (0)
+#else
+#define BT_STAMP(i)
+#define BT_STAMP7(pos, ch)
+#endif
 struct FtHeadGradSink {
     float *pw1;         // [G][n_inputs * out_w * w1_rows] per-chunk-group partials of dW1 (column-major like w1)
     size_t pw1_stride;  // floats per chunk group
 };
 
+// The workgroup's 16 waves have two roles. OCT_WAVES of them REDUCE: each walks its stream of rows of the chunk's octet
+// index, gathers rows of the staged gradient tile and adds what it has summed to the dW tile; the LDS array bounds them.
+// The other OCT_STAGERS (waves 0-3, one per SIMD, the oldest there and so first in the issue order) STAGE: they load the
+// next chunk's activations, form g = dout * f'(out), the bias sums and the head's dW on the matrix cores, keep the
+// result in registers and write it to the tile between the two barriers that separate chunks. So the global loads, the
+// activation derivative and the MFMAs of chunk c + 1 run beside the gathers of chunk c, on waves that never gather, the
+// tile needs no second buffer, and a reducing wave issues no vector-memory instruction but its own row fetches.
 template <bool PAIR, bool FUSED, bool GRP, bool HDW>
 __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_out, const FtFusedSrc &fs,
                                                 const float *__restrict__ out, const float *__restrict__ saved,
@@ -1536,6 +1577,7 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
                                                 const bt_ft_desc &d, int ntiles, int chunks_per_input, int chunks_per_wg,
                                                 const FtGrp &gp, int rows_cap, const FtHeadGradSink &hg) {
     static_assert(!HDW || (FUSED && !PAIR && !GRP), "HDW: fused single-output head over an ungrouped, unpaired table");
+    static_assert((OCT_WAVES + OCT_STAGERS) * 64 == LDS_THREADS && FT_CHUNK % (OCT_STAGERS * 8) == 0, "wave roles");
     extern __shared__ __align__(16) float lds_f[];
     const int tc = GRP ? gp.tile_cols : d.cols;
     float *acc = lds_f;                                 // [tc][32]
@@ -1563,88 +1605,19 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
     for (int q = threadIdx.x; q < tc * LDS_RT; q += LDS_THREADS) acc[q] = 0.0f;
     if (threadIdx.x < LDS_RT) gt[FT_CHUNK * LDS_RT + threadIdx.x] = 0.0f;
 
-    const int s8 = threadIdx.x & 7, el0 = threadIdx.x >> 3;  // staging role: 128 entries x 8 float4 per pass
-    int rg_e, rg_s;                                           // reduce role: group rg_e of the wave, float4 rg_s of the row
-    fwd_gather_slot(threadIdx.x & 63, rg_e, rg_s);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int grp = wv * 8 + rg_e;
-    float4 bsum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const bool stager = wv < OCT_STAGERS;
     const int c_lo = GRP ? g_clo : cg * chunks_per_wg, c_hi = GRP ? g_chi : min(nchunks, c_lo + chunks_per_wg);
-    constexpr int NPASS = FT_CHUNK / 128;
-    float4 r_go[NPASS], r_a[NPASS], r_b[NPASS];
-    int r_eid[NPASS], r_ne = 0;
-    uint32_t p_r0 = 0, p_r1 = 0, p_nfix = 0;  // the prefetched chunk's row range of this wave, its cut features
-    uint2 p_fix = make_uint2(0u, 0u);
-    oct_f32x4 hd[2];                          // HDW: dW1 accumulators [bucket rows 4 * (lane / 16) ..][column slot lane % 16]
+    // what the roles hand to the common epilogue
+    float4 bsum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // stagers: bias sums of this thread's tile columns
+    oct_f32x4 hd[2];                                     // stagers, HDW: dW1 accumulators [bucket rows 4 * (lane / 16) ..][column slot lane % 16]
 #pragma unroll
     for (int i = 0; i < 2; i++) hd[i] = oct_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    const uint32_t t_col = PAIR ? rt * 16 + (s8 & 3) * 4 : rt * LDS_RT + s8 * 4;
-    auto load_eids = [&](int c) {
-        if constexpr (GRP) {
-            const int4 ch = gp.chunks[min(c, c_hi - 1)];
-#pragma unroll
-            for (int pass = 0; pass < NPASS; pass++) r_eid[pass] = gp.elist[ch.y + min(el0 + pass * 128, ch.z - 1)];
-        }
-    };
-    // All loads of a prefetch are unconditional (rows past the chunk's end re-read its last entry and are dropped when
-    // the tile is staged): their number is then known to the compiler, and the stream waits in front of them stay exact.
-    auto prefetch = [&](int c) {
-        if constexpr (GRP) {
-            r_ne = gp.chunks[c].z;
-#pragma unroll
-            for (int pass = 0; pass < NPASS; pass++) {
-                const int e = r_eid[pass];
-                const int k = e >= d.batch ? 1 : 0, b = e - k * d.batch;
-                const size_t o_out = (size_t)b * d.out_ld + (size_t)k * out_w + t_col;
-                r_go[pass] = r_a[pass] = r_b[pass] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if constexpr (FUSED) {
-                    r_go[pass].x = fs.gz[b];
-                    r_go[pass].y = __int_as_float(fs.bucket ? fs.bucket[b] : 0);
-                    r_go[pass].z = __int_as_float(k);
-                } else {
-                    r_go[pass] = *reinterpret_cast<const float4 *>(grad_out + o_out);
-                }
-                if constexpr (PAIR) {
-                    const float *sv = saved + (size_t)e * d.rows + rt * 16 + (s8 & 3) * 4;
-                    r_a[pass] = *reinterpret_cast<const float4 *>(sv);
-                    r_b[pass] = *reinterpret_cast<const float4 *>(sv + half_rows);
-                } else {
-                    r_a[pass] = *reinterpret_cast<const float4 *>(out + o_out);
-                }
-            }
-            load_eids(c + 1);
-        } else {
-            // wave-uniform chunk base (SGPRs) + 32-bit per-lane element offsets
-            const int kc = c / chunks_per_input, b0 = (c % chunks_per_input) * FT_CHUNK;
-            const int n_e = min(FT_CHUNK, d.batch - b0);
-            r_ne = n_e;
-            const float *go_base = grad_out + (size_t)b0 * d.out_ld + (size_t)kc * out_w;
-            const float *out_base = out + (size_t)b0 * d.out_ld + (size_t)kc * out_w;
-            const float *sav_base = saved + ((size_t)kc * d.batch + b0) * d.rows;
-#pragma unroll
-            for (int pass = 0; pass < NPASS; pass++) {
-                const uint32_t el = (uint32_t)min(el0 + pass * 128, n_e - 1);
-                const uint32_t o_out = el * (uint32_t)d.out_ld + t_col;
-                r_go[pass] = r_a[pass] = r_b[pass] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if constexpr (FUSED) {
-                    r_go[pass].x = fs.gz[b0 + el];
-                    r_go[pass].y = __int_as_float(fs.bucket ? fs.bucket[b0 + el] : 0);
-                } else {
-                    r_go[pass] = *reinterpret_cast<const float4 *>(go_base + o_out);
-                }
-                if constexpr (PAIR) {
-                    const float *sv = sav_base + el * (uint32_t)d.rows + rt * 16 + (s8 & 3) * 4;
-                    r_a[pass] = *reinterpret_cast<const float4 *>(sv);
-                    r_b[pass] = *reinterpret_cast<const float4 *>(sv + half_rows);
-                } else {
-                    r_a[pass] = *reinterpret_cast<const float4 *>(out_base + o_out);
-                }
-            }
-        }
-        const uint16_t *hdr = reinterpret_cast<const uint16_t *>(meta + (size_t)c * OCT_META_BYTES);
-        p_r0 = hdr[wv], p_r1 = hdr[wv + 1], p_nfix = hdr[17];
-        p_fix = reinterpret_cast<const uint2 *>(meta + (size_t)c * OCT_META_BYTES + 64)[min(grp, OCT_FIX - 1)];
-    };
+    uint2 last_fix = make_uint2(0u, 0u);                 // reducers: the cut features of the last chunk
+    uint32_t last_nfix = 0;
+    int rg_e, rg_s;                                      // reduce role: group rg_e of the wave, float4 rg_s of the row
+    fwd_gather_slot(threadIdx.x & 63, rg_e, rg_s);
+    const int grp = (wv - OCT_STAGERS) * 8 + rg_e;       // (reducers)
     // parts of the cut runs of the chunk just reduced -> dW tile, in part order (one group per cut feature)
     auto fixup = [&](const uint2 fx, uint32_t nfix) {
         if ((uint32_t)grp < nfix) {
@@ -1657,84 +1630,204 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
             *dst = cur;
         }
     };
-    if (c_lo < c_hi) {
-        load_eids(c_lo);
-        prefetch(c_lo);
-    }
-    uint2 cur_fix = make_uint2(0u, 0u);
-    uint32_t cur_nfix = 0;
-    for (int c = c_lo; c < c_hi; c++) {
-        const int kc = GRP ? 0 : c / chunks_per_input;
-        const int n_e = r_ne;
-        lds_barrier();  // the previous chunk's readers are done with gt; its parts are complete
-        // this wave's stream of the chunk: rows [r0, r0 + n), n a multiple of 4; the first two 4-row sets now
-        const int r0 = __builtin_amdgcn_readfirstlane((int)p_r0), n = __builtin_amdgcn_readfirstlane((int)p_r1) - r0;
-        const uint2 *sp = stream + ((size_t)c * rows_cap + r0) * 8 + rg_e;
-        const int t1 = min(4, max(n - 4, 0));
-        uint2 qa0 = sp[0], qa1 = sp[8], qa2 = sp[16], qa3 = sp[24];
-        uint2 qb0 = sp[(t1 + 0) * 8], qb1 = sp[(t1 + 1) * 8], qb2 = sp[(t1 + 2) * 8], qb3 = sp[(t1 + 3) * 8];
-        fixup(cur_fix, cur_nfix);
-        cur_fix = p_fix, cur_nfix = __builtin_amdgcn_readfirstlane((int)p_nfix);
-#pragma unroll
-        for (int pass = 0; pass < NPASS; pass++) {
-            const int el = el0 + pass * 128;
-            if constexpr (HDW) {
-                // (whole wave: MFMA runs on all lanes; entries past the chunk's end count with gz = 0)
-                // A 16-lane row holds the entries 2k (lanes 0-7) and 2k + 1 (lanes 8-15), 8 lanes x float4 each. The
-                // B operand wants one entry per row (k = lane / 16), so the two halves trade half their float4
-                // (one DPP rotation by 8 lanes per value): afterwards the row holds entry 2k as 16 x float2 in
-                // (e0, e1) and entry 2k + 1 in (o0, o1), column 4 * (n & 7) + 2 * (n >> 3) + component for lane n.
-                const float gzv = el < n_e ? r_go[pass].x : 0.0f;
-                const int bk = __float_as_int(r_go[pass].y);
-                const float4 o = r_a[pass];
-                const float4 pv = make_float4(gzv * o.x, gzv * o.y, gzv * o.z, gzv * o.w);
-                const bool hi = (threadIdx.x >> 3) & 1;
-                const float x0 = row_ror8(hi ? pv.x : pv.z), x1 = row_ror8(hi ? pv.y : pv.w);  // from lane ^ 8
-                const float e0 = hi ? x0 : pv.x, e1 = hi ? x1 : pv.y;
-                const float o0 = hi ? pv.z : x0, o1 = hi ? pv.w : x1;
-                const int m = threadIdx.x & 15;
-                const float a_e = row_share<0>(bk) == m ? 1.0f : 0.0f, a_o = row_share<8>(bk) == m ? 1.0f : 0.0f;
-                hd[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_e, e0, hd[0], 0, 0, 0);
-                hd[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_e, e1, hd[1], 0, 0, 0);
-                hd[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, o0, hd[0], 0, 0, 0);
-                hd[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, o1, hd[1], 0, 0, 0);
-            }
-            if (el < n_e) {
-                float4 go = r_go[pass];
-                if constexpr (FUSED) {
-                    const float gzv = go.x;
-                    const int bk = __float_as_int(go.y);
-                    const int ke = GRP ? __float_as_int(go.z) : kc;
-                    const float4 wv4 = *reinterpret_cast<const float4 *>(
-                        w1t + (ke * fs.w1_rows + bk) * TW + (PAIR ? (s8 & 3) : s8) * 4);
-                    go = make_float4(gzv * wv4.x, gzv * wv4.y, gzv * wv4.z, gzv * wv4.w);
-                }
-                float4 g;
-                if constexpr (PAIR) {
-                    const float4 own = (s8 < 4) ? r_a[pass] : r_b[pass], oth = (s8 < 4) ? r_b[pass] : r_a[pass];
-                    const float4 dv = bt_act_deriv4(d.act, own);
-                    g = make_float4((go.x * oth.x) * dv.x, (go.y * oth.y) * dv.y, (go.z * oth.z) * dv.z,
-                                    (go.w * oth.w) * dv.w);
-                } else {
-                    const float4 dv = bt_act_deriv4(d.act, r_a[pass]);
-                    g = make_float4(go.x * dv.x, go.y * dv.y, go.z * dv.z, go.w * dv.w);
-                }
-                *reinterpret_cast<float4 *>(gt + el * LDS_RT + s8 * 4) = g;
-                bsum.x += g.x, bsum.y += g.y, bsum.z += g.z, bsum.w += g.w;
-            }
-        }
-        lds_barrier();
-        prefetch(min(c + 1, c_hi - 1));  // (the last chunk fetches itself again: unconditional on purpose, see above)
 
-        float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const char *gb = reinterpret_cast<const char *>(gt) + rg_s * 16;
-        auto row = [&](const uint2 q) {
-            const float4 v0 = *reinterpret_cast<const float4 *>(gb + (q.x & 0xff80u));
-            const float4 v1 = *reinterpret_cast<const float4 *>(gb + (q.x >> 16));
-            const float4 v2 = *reinterpret_cast<const float4 *>(gb + (q.y & 0xff80u));
-            const float4 v3 = *reinterpret_cast<const float4 *>(gb + (q.y >> 16));
-            add4(a, v0), add4(a, v1), add4(a, v2), add4(a, v3);
-            if (__builtin_amdgcn_readfirstlane((int)q.x) & 1) {  // last row of an octet: the whole wave ends its runs here
+    if (stager) {
+        // ---------------------------------------------------------------- stage: 256 threads, 8 lanes x float4 per entry
+        constexpr int SP = FT_CHUNK / (OCT_STAGERS * 8);  // passes: 32 entries of the chunk each
+        const int s8 = threadIdx.x & 7, el0 = threadIdx.x >> 3;
+        const uint32_t t_col = PAIR ? rt * 16 + (s8 & 3) * 4 : rt * LDS_RT + s8 * 4;
+        float4 g_reg[SP];
+        int r_eid[SP];
+        auto load_eids = [&](int c) {
+            if constexpr (GRP) {
+                const int4 ch = gp.chunks[min(c, c_hi - 1)];
+#pragma unroll
+                for (int pass = 0; pass < SP; pass++) r_eid[pass] = gp.elist[ch.y + min(el0 + pass * 32, ch.z - 1)];
+            }
+        };
+        // the activations of chunk cc -> its staged gradient in registers, the bias sums and the head's dW.
+        // (rows past the chunk's end re-read its last entry and count as zero)
+        auto stage = [&](int cc) {
+            int n_e, kc = 0;
+            const float *go_base = grad_out, *out_base = out, *sav_base = saved;
+            int b0 = 0;
+            if constexpr (GRP) {
+                n_e = gp.chunks[cc].z;
+            } else {
+                kc = cc / chunks_per_input, b0 = (cc % chunks_per_input) * FT_CHUNK;
+                n_e = min(FT_CHUNK, d.batch - b0);
+                go_base = grad_out + (size_t)b0 * d.out_ld + (size_t)kc * out_w;
+                out_base = out + (size_t)b0 * d.out_ld + (size_t)kc * out_w;
+                sav_base = saved + ((size_t)kc * d.batch + b0) * d.rows;
+            }
+            float4 r_go[SP], r_a[SP], r_b[SP];
+#pragma unroll
+            for (int pass = 0; pass < SP; pass++) {
+                r_go[pass] = r_a[pass] = r_b[pass] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if constexpr (GRP) {
+                    const int e = r_eid[pass];
+                    const int k = e >= d.batch ? 1 : 0, b = e - k * d.batch;
+                    const size_t o_out = (size_t)b * d.out_ld + (size_t)k * out_w + t_col;
+                    if constexpr (FUSED) {
+                        r_go[pass].x = fs.gz[b];
+                        r_go[pass].y = __int_as_float(fs.bucket ? fs.bucket[b] : 0);
+                        r_go[pass].z = __int_as_float(k);
+                    } else {
+                        r_go[pass] = *reinterpret_cast<const float4 *>(grad_out + o_out);
+                    }
+                    if constexpr (PAIR) {
+                        const float *sv = saved + (size_t)e * d.rows + rt * 16 + (s8 & 3) * 4;
+                        r_a[pass] = *reinterpret_cast<const float4 *>(sv);
+                        r_b[pass] = *reinterpret_cast<const float4 *>(sv + half_rows);
+                    } else {
+                        r_a[pass] = *reinterpret_cast<const float4 *>(out + o_out);
+                    }
+                } else {
+                    const uint32_t el = (uint32_t)min(el0 + pass * 32, n_e - 1);
+                    const uint32_t o_out = el * (uint32_t)d.out_ld + t_col;
+                    if constexpr (FUSED) {
+                        r_go[pass].x = fs.gz[b0 + el];
+                        r_go[pass].y = __int_as_float(fs.bucket ? fs.bucket[b0 + el] : 0);
+                    } else {
+                        r_go[pass] = *reinterpret_cast<const float4 *>(go_base + o_out);
+                    }
+                    if constexpr (PAIR) {
+                        const float *sv = sav_base + el * (uint32_t)d.rows + rt * 16 + (s8 & 3) * 4;
+                        r_a[pass] = *reinterpret_cast<const float4 *>(sv);
+                        r_b[pass] = *reinterpret_cast<const float4 *>(sv + half_rows);
+                    } else {
+                        r_a[pass] = *reinterpret_cast<const float4 *>(out_base + o_out);
+                    }
+                }
+            }
+            load_eids(cc + 1);  // (GRP) the entry ids of the chunk after this one, for the next call
+#pragma unroll
+            for (int pass = 0; pass < SP; pass++) {
+                const int el = el0 + pass * 32;
+                if constexpr (HDW) {
+                    // (whole wave: MFMA runs on all lanes; entries past the chunk's end count with gz = 0)
+                    // A 16-lane row holds the entries 2k (lanes 0-7) and 2k + 1 (lanes 8-15), 8 lanes x float4 each. The
+                    // B operand wants one entry per row (k = lane / 16), so the two halves trade half their float4
+                    // (one DPP rotation by 8 lanes per value): afterwards the row holds entry 2k as 16 x float2 in
+                    // (e0, e1) and entry 2k + 1 in (o0, o1), column 4 * (n & 7) + 2 * (n >> 3) + component for lane n.
+                    const float gzv = el < n_e ? r_go[pass].x : 0.0f;
+                    const int bk = __float_as_int(r_go[pass].y);
+                    const float4 o = r_a[pass];
+                    const float4 pv = make_float4(gzv * o.x, gzv * o.y, gzv * o.z, gzv * o.w);
+                    const bool hi = (threadIdx.x >> 3) & 1;
+                    const float x0 = row_ror8(hi ? pv.x : pv.z), x1 = row_ror8(hi ? pv.y : pv.w);  // from lane ^ 8
+                    const float e0 = hi ? x0 : pv.x, e1 = hi ? x1 : pv.y;
+                    const float o0 = hi ? pv.z : x0, o1 = hi ? pv.w : x1;
+                    const int m = threadIdx.x & 15;
+                    const float a_e = row_share<0>(bk) == m ? 1.0f : 0.0f, a_o = row_share<8>(bk) == m ? 1.0f : 0.0f;
+                    hd[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_e, e0, hd[0], 0, 0, 0);
+                    hd[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_e, e1, hd[1], 0, 0, 0);
+                    hd[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, o0, hd[0], 0, 0, 0);
+                    hd[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, o1, hd[1], 0, 0, 0);
+                }
+                float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (el < n_e) {
+                    float4 go = r_go[pass];
+                    if constexpr (FUSED) {
+                        const float gzv = go.x;
+                        const int bk = __float_as_int(go.y);
+                        const int ke = GRP ? __float_as_int(go.z) : kc;
+                        const float4 wv4 = *reinterpret_cast<const float4 *>(
+                            w1t + (ke * fs.w1_rows + bk) * TW + (PAIR ? (s8 & 3) : s8) * 4);
+                        go = make_float4(gzv * wv4.x, gzv * wv4.y, gzv * wv4.z, gzv * wv4.w);
+                    }
+                    if constexpr (PAIR) {
+                        const float4 own = (s8 < 4) ? r_a[pass] : r_b[pass], oth = (s8 < 4) ? r_b[pass] : r_a[pass];
+                        const float4 dv = bt_act_deriv4(d.act, own);
+                        g = make_float4((go.x * oth.x) * dv.x, (go.y * oth.y) * dv.y, (go.z * oth.z) * dv.z,
+                                        (go.w * oth.w) * dv.w);
+                    } else {
+                        const float4 dv = bt_act_deriv4(d.act, r_a[pass]);
+                        g = make_float4(go.x * dv.x, go.y * dv.y, go.z * dv.z, go.w * dv.w);
+                    }
+                    bsum.x += g.x, bsum.y += g.y, bsum.z += g.z, bsum.w += g.w;
+                }
+                g_reg[pass] = g;
+            }
+        };
+#ifdef BT_OCT_STAGER_PRIO
+        __builtin_amdgcn_s_setprio(BT_OCT_STAGER_PRIO);
+#endif
+        if (c_lo < c_hi) {
+            load_eids(c_lo);
+            stage(c_lo);
+        }
+        for (int c = c_lo; c < c_hi; c++) {
+            BT_STAMP(0);
+            lds_barrier();  // the previous chunk's readers are done with the tile
+            BT_STAMP(1);
+#pragma unroll
+            for (int pass = 0; pass < SP; pass++)
+                *reinterpret_cast<float4 *>(gt + (el0 + pass * 32) * LDS_RT + s8 * 4) = g_reg[pass];
+            BT_STAMP(2);
+            lds_barrier();
+            BT_STAMP(3);
+            if (c + 1 < c_hi) stage(c + 1);
+            BT_STAMP(5);
+        }
+    } else {
+        // ---------------------------------------------------------------- reduce
+        const int rw = wv - OCT_STAGERS;
+        uint32_t m_r0 = 0, m_r1 = 0, m_nfix = 0;  // meta of the next chunk: this wave's row range, the cut features
+        uint2 m_fix = make_uint2(0u, 0u);
+        auto load_meta = [&](int c) {
+            const uint16_t *hdr = reinterpret_cast<const uint16_t *>(meta + (size_t)c * OCT_META_BYTES);
+            m_r0 = hdr[rw], m_r1 = hdr[rw + 1], m_nfix = hdr[17];
+            m_fix = reinterpret_cast<const uint2 *>(meta + (size_t)c * OCT_META_BYTES + 64)[min(grp, OCT_FIX - 1)];
+        };
+        // this wave's stream of a chunk: rows [r0, r0 + n), n a multiple of 4; the first two 4-row sets
+        uint2 qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;
+        qa0 = qa1 = qa2 = qa3 = qb0 = qb1 = qb2 = qb3 = make_uint2(0u, 0u);
+        auto first_rows = [&](int c, int r0, int n) {
+            const uint2 *sp = stream + ((size_t)c * rows_cap + r0) * 8 + rg_e;
+            const int t1 = min(4, max(n - 4, 0));
+            qa0 = sp[0], qa1 = sp[8], qa2 = sp[16], qa3 = sp[24];
+            qb0 = sp[(t1 + 0) * 8], qb1 = sp[(t1 + 1) * 8], qb2 = sp[(t1 + 2) * 8], qb3 = sp[(t1 + 3) * 8];
+        };
+        int n_r0 = 0, n_n = 0;  // row range of the chunk about to be reduced
+#ifdef BT_OCT_STATIC_PRIO
+        // the waves of a SIMD issue oldest-first: a fixed priority for the younger reducers keeps the three level
+        if (rw >= 8) __builtin_amdgcn_s_setprio(2);
+        else if (rw >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+        if (c_lo < c_hi) {
+            load_meta(c_lo);
+            n_r0 = __builtin_amdgcn_readfirstlane((int)m_r0), n_n = __builtin_amdgcn_readfirstlane((int)m_r1) - n_r0;
+            first_rows(c_lo, n_r0, n_n);
+        }
+        for (int c = c_lo; c < c_hi; c++) {
+            const int r0 = n_r0, n = n_n;
+            const uint2 cur_fix = m_fix;
+            const uint32_t cur_nfix = __builtin_amdgcn_readfirstlane((int)m_nfix);
+            BT_STAMP(0);
+            lds_barrier();  // every wave is done with the previous chunk: its parts are complete
+            BT_STAMP(1);
+            fixup(last_fix, last_nfix);
+            last_fix = cur_fix, last_nfix = cur_nfix;
+            load_meta(min(c + 1, c_hi - 1));
+            BT_STAMP(2);
+            lds_barrier();  // the tile holds this chunk's gradient
+            BT_STAMP(3);
+
+            const uint2 *sp = stream + ((size_t)c * rows_cap + r0) * 8 + rg_e;
+            float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const char *gb = reinterpret_cast<const char *>(gt) + rg_s * 16;
+            // Two rows in flight: the gathers of row r + 1 are issued before the sums of row r are taken, so a wave keeps
+            // eight ds_read_b128 outstanding and its adds and address arithmetic run under the LDS latency. (Reading the dW
+            // row of a flush in front of the flagged row's own gathers, so that the flush never drains the wave's LDS
+            // queue, was measured and is slower: +8 us.)
+            float4 va0, va1, va2, va3, vb0, vb1, vb2, vb3;
+#define ISSUE(V, Q)                                                              \
+    V##0 = *reinterpret_cast<const float4 *>(gb + ((Q).x & 0xff80u)),            \
+    V##1 = *reinterpret_cast<const float4 *>(gb + ((Q).x >> 16)),                \
+    V##2 = *reinterpret_cast<const float4 *>(gb + ((Q).y & 0xff80u)),            \
+    V##3 = *reinterpret_cast<const float4 *>(gb + ((Q).y >> 16))
+            auto flush = [&](const uint2 q) {  // last row of an octet: the whole wave ends its runs here
                 const uint32_t kind = (q.x >> 1) & 3u, id = ((q.x >> 3) & 15u) | ((q.y & 127u) << 4);
                 if (kind == 1u) {
                     float4 *dst = reinterpret_cast<float4 *>(acc + id * LDS_RT + rg_s * 4);
@@ -1745,42 +1838,74 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
                     *reinterpret_cast<float4 *>(parts + id * LDS_RT + rg_s * 4) = a;
                 }
                 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            };
+#define CONSUME(V, Q)                                                            \
+    do {                                                                         \
+        add4(a, V##0), add4(a, V##1), add4(a, V##2), add4(a, V##3);              \
+        if (__builtin_amdgcn_readfirstlane((int)(Q).x) & 1) flush(Q);            \
+    } while (0)
+            // a set of four rows whose first row's gathers are in flight (in va); NEXT: the first row of the set behind it
+#define SET4(Q0, Q1, Q2, Q3, HAS_NEXT, NEXT) \
+    do {                                     \
+        ISSUE(vb, Q1);                       \
+        CONSUME(va, Q0);                     \
+        ISSUE(va, Q2);                       \
+        CONSUME(vb, Q1);                     \
+        ISSUE(vb, Q3);                       \
+        CONSUME(va, Q2);                     \
+        if (HAS_NEXT) ISSUE(va, NEXT);       \
+        CONSUME(vb, Q3);                     \
+    } while (0)
+            // rows t .. t+3 of the stream (clamped to its last set: a short stream re-reads rows it never uses)
+            auto fetch = [&](int t, uint2 &x0, uint2 &x1, uint2 &x2, uint2 &x3) {
+                const int tt = min(t, max(n - 4, 0));
+                x0 = sp[(tt + 0) * 8], x1 = sp[(tt + 1) * 8], x2 = sp[(tt + 2) * 8], x3 = sp[(tt + 3) * 8];
+            };
+            // sets 0 and 1 (qa, qb) were fetched at the end of the chunk before; every later set one set ahead
+#ifndef BT_OCT_PRIO
+#define BT_OCT_PRIO 1
+#endif
+#if BT_OCT_PRIO > 0
+            // The waves of a SIMD issue oldest-first: with equal work the older reducers run ahead and the youngest
+            // finishes the chunk alone. Rotating the issue priority among the three every BT_OCT_PRIO sets keeps them level.
+            const int wq3 = rw >> 2;  // position among the three reducing waves of this SIMD
+            auto prio = [&](int k) {
+                switch ((k / BT_OCT_PRIO + wq3) % 3) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                default: __builtin_amdgcn_s_setprio(2); break;
+                }
+            };
+#else
+            auto prio = [&](int) {};
+#endif
+            if (0 < n) {
+                ISSUE(va, qa0);
+                for (int t = 0;; t += 8) {
+                    const bool has_b = t + 4 < n;
+                    prio(t >> 2);
+                    SET4(qa0, qa1, qa2, qa3, has_b, qb0);
+                    fetch(t + 8, qa0, qa1, qa2, qa3);
+                    if (!has_b) break;
+                    const bool has_a = t + 8 < n;
+                    prio((t >> 2) + 1);
+                    SET4(qb0, qb1, qb2, qb3, has_a, qa0);
+                    fetch(t + 12, qb0, qb1, qb2, qb3);
+                    if (!has_a) break;
+                }
             }
-        };
-        // rows t .. t+3 of the stream (clamped to its last set: a short stream re-reads rows it never uses)
-        auto fetch = [&](int t, uint2 &x0, uint2 &x1, uint2 &x2, uint2 &x3) {
-            const int tt = min(t, max(n - 4, 0));
-            x0 = sp[(tt + 0) * 8], x1 = sp[(tt + 1) * 8], x2 = sp[(tt + 2) * 8], x3 = sp[(tt + 3) * 8];
-        };
-        // The four waves of a SIMD issue oldest-first: with equal work the low wave ids run ahead and the last ones
-        // finish the chunk alone, the LDS half idle, while the others wait at the barrier. Rotating the issue priority
-        // every two rows keeps the four level (-3 us; every four rows: -2.5, every eight: worse at low occupancy).
-        const int wq = wv >> 2;  // position among the four waves of this SIMD
-        auto prio = [&](int k) {
-            if constexpr (GRP) return;  // (segment-grouped tables: other kernels share the CUs then, and it costs 1-2 %)
-            switch ((k + wq) & 3) {
-            case 0: __builtin_amdgcn_s_setprio(0); break;
-            case 1: __builtin_amdgcn_s_setprio(1); break;
-            case 2: __builtin_amdgcn_s_setprio(2); break;
-            default: __builtin_amdgcn_s_setprio(3); break;
-            }
-        };
-#define ROWS4(S, A, B, C, D) prio(2 * (S)), row(A), row(B), prio(2 * (S) + 1), row(C), row(D)
-        // peeled: sets 0 and 1 were fetched before the staging loads of the next chunk
-        if (0 < n) ROWS4(0, qa0, qa1, qa2, qa3);
-        fetch(8, qa0, qa1, qa2, qa3);
-        if (4 < n) ROWS4(1, qb0, qb1, qb2, qb3);
-        fetch(12, qb0, qb1, qb2, qb3);
-        for (int t = 8; t < n; t += 8) {
-            ROWS4(t >> 2, qa0, qa1, qa2, qa3);
-            fetch(t + 8, qa0, qa1, qa2, qa3);
-            if (t + 4 < n) ROWS4((t >> 2) + 1, qb0, qb1, qb2, qb3);
-            fetch(t + 12, qb0, qb1, qb2, qb3);
+#undef SET4
+#undef CONSUME
+#undef ISSUE
+            BT_STAMP(5);
+            // the next chunk's first rows (the last chunk fetches its own again: every load is unconditional)
+            n_r0 = __builtin_amdgcn_readfirstlane((int)m_r0), n_n = __builtin_amdgcn_readfirstlane((int)m_r1) - n_r0;
+            first_rows(min(c + 1, c_hi - 1), n_r0, n_n);
+            BT_STAMP(6);
         }
-#undef ROWS4
     }
     __syncthreads();
-    fixup(cur_fix, cur_nfix);
+    if (!stager) fixup(last_fix, last_nfix);
     __syncthreads();
     float *pw = partial_w + (size_t)cg * tc * d.stride;
     for (int q = threadIdx.x; q < tc * 8; q += LDS_THREADS) {
@@ -1788,42 +1913,38 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
         *reinterpret_cast<float4 *>(pw + (size_t)f * d.stride + d.offset + tile_row(PAIR, rt, half_rows, t8 * 4)) =
             *reinterpret_cast<const float4 *>(acc + f * LDS_RT + t8 * 4);
     }
-    // bias partial: fixed-order sum over the 128 staging thread groups, in two levels (8 x 16)
-    *reinterpret_cast<float4 *>(gt + el0 * LDS_RT + s8 * 4) = bsum;
-    __syncthreads();
-    float bpart = 0.0f;
-    if (threadIdx.x < 8 * LDS_RT) {
-        const int col = threadIdx.x & (LDS_RT - 1), part = threadIdx.x / LDS_RT;
-        for (int i = 0; i < 16; i++) bpart += gt[(part * 16 + i) * LDS_RT + col];
-    }
-    __syncthreads();
-    if (threadIdx.x < 8 * LDS_RT) gt[threadIdx.x] = bpart;
+    // bias partial: fixed-order sum over the 32 staging thread groups (8 lanes x float4 each)
+    constexpr int SG = OCT_STAGERS * 8;
+    if (stager) *reinterpret_cast<float4 *>(gt + (threadIdx.x >> 3) * LDS_RT + (threadIdx.x & 7) * 4) = bsum;
     __syncthreads();
     if (threadIdx.x < LDS_RT) {
-        float s = 0.0f;
-        for (int i = 0; i < 8; i++) s += gt[i * LDS_RT + threadIdx.x];
-        partial_b[(size_t)cg * d.rows + tile_row(PAIR, rt, half_rows, threadIdx.x)] = s;
+        float sb = 0.0f;
+        for (int i = 0; i < SG; i++) sb += gt[i * LDS_RT + threadIdx.x];
+        partial_b[(size_t)cg * d.rows + tile_row(PAIR, rt, half_rows, threadIdx.x)] = sb;
     }
     if constexpr (HDW) {
-        // the waves' dW1 accumulators -> one partial per (bucket, column) of this tile, the waves in order.
-        // The dW tile has been written out (barriers above), so its LDS holds the 16 x w1_rows x 32 floats.
+        // the staging waves' dW1 accumulators -> one partial per (bucket, column) of this tile, the waves in order.
+        // The dW tile has been written out (barriers above), so its LDS holds the OCT_STAGERS x w1_rows x 32 floats.
         float *tmp = acc;
         const int lane = threadIdx.x & 63, qd = lane >> 4, j = lane & 15;
+        __syncthreads();  // (every thread has read its part of the dW tile)
+        if (stager) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int m = 4 * qd + r;
-            if (m < fs.w1_rows) {
-                float *t2 = tmp + ((size_t)wv * fs.w1_rows + m) * 32 + 4 * (j & 7) + 2 * (j >> 3);
-                t2[0] = hd[0][r], t2[1] = hd[1][r];
+            for (int r = 0; r < 4; r++) {
+                const int m = 4 * qd + r;
+                if (m < fs.w1_rows) {
+                    float *t2 = tmp + ((size_t)wv * fs.w1_rows + m) * 32 + 4 * (j & 7) + 2 * (j >> 3);
+                    t2[0] = hd[0][r], t2[1] = hd[1][r];
+                }
             }
         }
         __syncthreads();
         const int kk = c_lo / chunks_per_input;  // the one input all chunks of this workgroup belong to (host-checked)
         for (int q = threadIdx.x; q < fs.w1_rows * 32; q += LDS_THREADS) {
             const int m = q >> 5, col = q & 31;
-            float s = 0.0f;
-            for (int w2 = 0; w2 < OCT_WAVES; w2++) s += tmp[((size_t)w2 * fs.w1_rows + m) * 32 + col];
-            hg.pw1[(size_t)cg * hg.pw1_stride + (size_t)(kk * out_w + rt * 32 + col) * fs.w1_rows + m] = s;
+            float sh = 0.0f;
+            for (int w2 = 0; w2 < OCT_STAGERS; w2++) sh += tmp[((size_t)w2 * fs.w1_rows + m) * 32 + col];
+            hg.pw1[(size_t)cg * hg.pw1_stride + (size_t)(kk * out_w + rt * 32 + col) * fs.w1_rows + m] = sh;
         }
     }
 }
@@ -2219,7 +2340,7 @@ int ft_plan(const bt_ft_desc *d, FtPlan *p) {
     // (every chunk of a workgroup must belong to one input; the waves' accumulators are merged through the dW tile's LDS)
     p->pw1_stride = (size_t)d->n_inputs * d->rows * FtPlan::kFusedMaxRows;
     p->hdw = p->oct && !p->grouped && !d->pairwise && p->chunks_per_input % p->chunks_per_wg == 0 &&
-             (size_t)p->tc * LDS_RT >= (size_t)OCT_WAVES * FtPlan::kFusedMaxRows * 64;
+             (size_t)p->tc * LDS_RT >= (size_t)OCT_STAGERS * FtPlan::kFusedMaxRows * 64;
     if (p->hdw) p->off_pw1 = o, o += bt_align((size_t)p->G * p->pw1_stride * sizeof(float));
     p->total = o;
     return BT_OK;
@@ -2587,6 +2708,12 @@ int bt_internal_ft_build_sorted(void *stream, const bt_ft_desc *d, const int32_t
 
 // tests change the switches between cases of one process: they call this after touching the environment
 extern "C" void bt_internal_reload_env(void) { g_ft_env.reload(); }
+#ifdef BT_STAMPS
+extern "C" int bt_internal_read_stamps(void *dst, size_t bytes) {
+    BT_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(bt_stamps), std::min(bytes, sizeof(bt_stamps))));
+    return BT_OK;
+}
+#endif
 
 bool bt_internal_ft_grouped(const bt_ft_desc *d) {
     FtPlan p;
