@@ -861,6 +861,17 @@ __device__ __forceinline__ uint32_t oct_group_bcast(uint32_t v) {
     return (uint32_t)t;
 }
 
+// 16 bytes at an LDS byte address (an integer, not a pointer derived from the dynamic LDS symbol: the compiler leaves an
+// add of the symbol's base, 0, on every address formed from the pointer)
+typedef float lds_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 lds_load4(uint32_t byte_addr) {
+    const lds_f32x4 t = *(const __attribute__((address_space(3))) lds_f32x4 *)(uintptr_t)byte_addr;
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void *p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p;
+}
+
 __device__ __forceinline__ int tile_row(bool pair, int rt, int half_rows, int local4) {
     // local4: float offset (multiple of 2 or 4) inside the 32-float tile -> global row
     if (!pair) return rt * LDS_RT + local4;
@@ -1580,9 +1591,10 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
     static_assert((OCT_WAVES + OCT_STAGERS) * 64 == LDS_THREADS && FT_CHUNK % (OCT_STAGERS * 8) == 0, "wave roles");
     extern __shared__ __align__(16) float lds_f[];
     const int tc = GRP ? gp.tile_cols : d.cols;
-    float *acc = lds_f;                                 // [tc][32]
-    float *gt = acc + (size_t)tc * LDS_RT;              // [FT_CHUNK + 1][32], last row = zeros (padding target)
-    float *parts = gt + (FT_CHUNK + 1) * LDS_RT;        // [OCT_SLOTS][32] sums of the parts of cut runs
+    // (the gradient tile sits at LDS offset 0: a gather's address is then (row offset) | (lane's 16 bytes), one v_and_or)
+    float *gt = lds_f;                                  // [FT_CHUNK + 1][32], last row = zeros (padding target)
+    float *acc = gt + (FT_CHUNK + 1) * LDS_RT;          // [tc][32]
+    float *parts = acc + (size_t)tc * LDS_RT;           // [OCT_SLOTS][32] sums of the parts of cut runs
     float *w1t = parts + OCT_SLOTS * LDS_RT;            // FUSED: [n_inputs][w1_rows][TW]
     const int rt = blockIdx.x % ntiles, cg = blockIdx.x / ntiles;
     const int half_rows = d.rows / 2;
@@ -1604,6 +1616,7 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
     }
     for (int q = threadIdx.x; q < tc * LDS_RT; q += LDS_THREADS) acc[q] = 0.0f;
     if (threadIdx.x < LDS_RT) gt[FT_CHUNK * LDS_RT + threadIdx.x] = 0.0f;
+    if (lds_addr_of(gt) & 127u) __builtin_trap();  // (folds away: this kernel has no static LDS in front of the tile)
 
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool stager = wv < OCT_STAGERS;
@@ -1816,17 +1829,27 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
 
             const uint2 *sp = stream + ((size_t)c * rows_cap + r0) * 8 + rg_e;
             float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            const char *gb = reinterpret_cast<const char *>(gt) + rg_s * 16;
+            const uint32_t lane16 = lds_addr_of(gt) + (uint32_t)rg_s * 16;  // (the tile's LDS address is 0, checked above)
             // Two rows in flight: the gathers of row r + 1 are issued before the sums of row r are taken, so a wave keeps
             // eight ds_read_b128 outstanding and its adds and address arithmetic run under the LDS latency. (Reading the dW
             // row of a flush in front of the flagged row's own gathers, so that the flush never drains the wave's LDS
             // queue, was measured and is slower: +8 us.)
             float4 va0, va1, va2, va3, vb0, vb1, vb2, vb3;
-#define ISSUE(V, Q)                                                              \
-    V##0 = *reinterpret_cast<const float4 *>(gb + ((Q).x & 0xff80u)),            \
-    V##1 = *reinterpret_cast<const float4 *>(gb + ((Q).x >> 16)),                \
-    V##2 = *reinterpret_cast<const float4 *>(gb + ((Q).y & 0xff80u)),            \
-    V##3 = *reinterpret_cast<const float4 *>(gb + ((Q).y >> 16))
+#ifdef BT_X_PARITY  // timing-only experiment: every gather forced onto the bank half of its group (wrong sums)
+            const uint32_t pmask = BT_X_PARITY ? 0xff00u : (0xff80u | (uint32_t)(rows_cap >> 30));
+            const uint32_t pm = BT_X_PARITY ? (uint32_t)(rg_e & 1) << 7 : (uint32_t)(rows_cap >> 30);
+#define ISSUE(V, Q)                                                                         \
+    V##0 = lds_load4((((Q).x) & pmask) | pm | lane16),                \
+    V##1 = lds_load4((((Q).x >> 16) & pmask) | pm | lane16),          \
+    V##2 = lds_load4((((Q).y) & pmask) | pm | lane16),                \
+    V##3 = lds_load4((((Q).y >> 16) & pmask) | pm | lane16)
+#else
+#define ISSUE(V, Q)                                          \
+    V##0 = lds_load4(((Q).x & 0xff80u) | lane16),            \
+    V##1 = lds_load4(((Q).x >> 16) + lane16),                \
+    V##2 = lds_load4(((Q).y & 0xff80u) | lane16),            \
+    V##3 = lds_load4(((Q).y >> 16) + lane16)
+#endif
             auto flush = [&](const uint2 q) {  // last row of an octet: the whole wave ends its runs here
                 const uint32_t kind = (q.x >> 1) & 3u, id = ((q.x >> 3) & 15u) | ((q.y & 127u) << 4);
                 if (kind == 1u) {
