@@ -459,7 +459,7 @@ __host__ __device__ inline int oct_rows_cap(int nnz, int tc) {
 }
 __host__ __device__ inline size_t oct_index_lds_bytes(int tc) {
     const int IC = oct_item_cap(tc);
-    return ((size_t)(OCT_IDX_THREADS / 64) * tc + 2 * IC + IC / 8 + 16 + 16 + 64 + 24) * 4 +
+    return ((size_t)(OCT_IDX_THREADS / 64 + 1) * tc + 2 * IC + IC / 8 + 16 + 16 + 64 + 24) * 4 +
            ((size_t)((tc + 1) & ~1) + 3 * IC + IC / 8 + (size_t)(IC / 64 + 1) * 64) * 2;
 }
 __device__ __forceinline__ int oct_wave_of(int o) {  // serpentine deal of octet o (sorted by length) to the waves
@@ -480,8 +480,15 @@ __global__ __launch_bounds__(OCT_IDX_THREADS, 6) void ft_index_oct_kernel(const 
     constexpr int T = OCT_IDX_THREADS, NW = T / 64;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int IC = oct_item_cap(cols);
-    uint32_t *cnt = lds;                     // [NW][cols] pairs per (wave, feature) -> within-run start of the wave
-    uint32_t *idest = cnt + NW * cols;       // [IC] dest word of an item (a run or a part of one)
+    // Pairs are counted by the parity of their position (the low / high half of a word: even / odd rows of the staged
+    // tile lie in different halves of the LDS banks, and the two groups that share a ds_read_b128 pass collide when
+    // their rows have equal parity). A run lists the positions of one parity first, then the other -- which one first
+    // depends on the lane group the run lands in (even groups: even rows first), so that the two groups of a pass read
+    // opposite halves for most of a run. Inside a parity the positions stay in ascending order: the order of every sum
+    // is still a function of the batch alone.
+    uint32_t *cnt = lds;                     // [NW][cols] pairs per (wave, feature), even | odd << 16 -> starts of the wave
+    uint32_t *tpar = cnt + NW * cols;        // [cols] pairs of the feature, even | odd << 16
+    uint32_t *idest = tpar + cols;           // [IC] dest word of an item (a run or a part of one)
     uint32_t *itembase = idest + IC;         // [IC] u16 index of the item's first offset in the chunk's stream
     uint32_t *omax = itembase + IC;          // [IC/8] length of an octet = its longest item
     uint32_t *tsum = omax + IC / 8;          // [16] scan scratch
@@ -551,7 +558,7 @@ __global__ __launch_bounds__(OCT_IDX_THREADS, 6) void ft_index_oct_kernel(const 
     auto count_step = [&](int e, int j) {
         const int nvalid = n_valid(e, j);
         if (e < e_hi && li < nvalid) {
-            if (in_seg(j - col0)) atomicAdd(&cnt[(size_t)wave * cols + (j - col0)], 1u);
+            if (in_seg(j - col0)) atomicAdd(&cnt[(size_t)wave * cols + (j - col0)], (e & 1) ? 0x10000u : 1u);
             else if constexpr (GRP) atomicAdd(gp.viol, 1);
         }
     };
@@ -573,9 +580,11 @@ __global__ __launch_bounds__(OCT_IDX_THREADS, 6) void ft_index_oct_kernel(const 
             uint32_t t = 0;
             for (int w2 = 0; w2 < NW; w2++) {
                 const uint32_t v = cnt[(size_t)w2 * cols + f];
-                cnt[(size_t)w2 * cols + f] = t;  // pairs of f in the waves before w2: ascending entry order inside a run
+                cnt[(size_t)w2 * cols + f] = t;  // pairs of f in the waves before w2 (per parity): ascending entry order
                 t += v;
             }
+            tpar[f] = t;
+            t = (t & 0xffffu) + (t >> 16);
             item0[f] = (uint16_t)t;
             const uint32_t blocks = (t + 3) >> 2;
 #pragma unroll
@@ -718,8 +727,12 @@ __global__ __launch_bounds__(OCT_IDX_THREADS, 6) void ft_index_oct_kernel(const 
         const bool active = (e < e_hi) && (li < nvalid) && in_seg(j);
         uint32_t i = 0;
         for (int q = 0; q < eps; q++)
-            if (active && sub == q) i = atomicAdd(&start[j], 1u);
+            if (active && sub == q) i = atomicAdd(&start[j], (e & 1) ? 0x10000u : 1u);
         if (active) {
+            // rank inside the run: the group's preferred parity first (the group = the sorted position of the run's first item)
+            const uint32_t tp = tpar[j], odd = (uint32_t)e & 1u, pref = (uint32_t)ipos[item0[j]] & 1u;
+            const uint32_t mine = odd ? i >> 16 : i & 0xffffu, before = pref ? tp >> 16 : tp & 0xffffu;
+            i = odd == pref ? mine : before + mine;
             const uint32_t within = i & in_mask;
             s16[itembase[item0[j] + (i >> (ls + 2))] + (within >> 2) * 32 + (within & 3)] = (uint16_t)(e << 7);
         }
