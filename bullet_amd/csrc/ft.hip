@@ -17,6 +17,7 @@
 // Every dW element is then summed chunk by chunk, entry by entry, in that fixed order: the result is
 // bit-identical run to run (the reference's atomicAdd order is arbitrary).
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 #include "common.h"
@@ -1579,6 +1580,7 @@ __device__ unsigned long long bt_stamps[BT_STAMP_WGS][16][BT_STAMP_CHUNKS][BT_ST
     } while (0)
 #else
 #define BT_STAMP(i)
+#define BT_STAMPC(i, ch)
 #define BT_STAMP7(pos, ch)
 #endif
 struct FtHeadGradSink {
@@ -1657,143 +1659,171 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
         }
     };
 
-    if (stager) {
-        // ---------------------------------------------------------------- stage: 256 threads, 8 lanes x float4 per entry
-        constexpr int SP = FT_CHUNK / (OCT_STAGERS * 8);  // passes: 32 entries of the chunk each
-        const int s8 = threadIdx.x & 7, el0 = threadIdx.x >> 3;
-        const uint32_t t_col = PAIR ? rt * 16 + (s8 & 3) * 4 : rt * LDS_RT + s8 * 4;
-        float4 g_reg[SP];
-        int r_eid[SP];
-        auto load_eids = [&](int c) {
-            if constexpr (GRP) {
-                const int4 ch = gp.chunks[min(c, c_hi - 1)];
+    // ---- staging, for any number of passes NP over entries tg, tg + stride, ...: 8 lanes x float4 per entry
+    const int s8 = threadIdx.x & 7;
+    const uint32_t t_col = PAIR ? rt * 16 + (s8 & 3) * 4 : rt * LDS_RT + s8 * 4;
+    // PAIR: the lane holds its own half's activations; the other half's come from lane ^ 4 when the product is formed
+    const uint32_t sv_col = rt * 16 + (s8 & 3) * 4 + ((s8 & 4) ? half_rows : 0);
+    auto load_eids = [&](auto np, int stride, int tg, int *r_eid, int c) {
+        if constexpr (GRP) {
+            const int4 ch = gp.chunks[min(c, c_hi - 1)];
 #pragma unroll
-                for (int pass = 0; pass < SP; pass++) r_eid[pass] = gp.elist[ch.y + min(el0 + pass * 32, ch.z - 1)];
-            }
-        };
-        // the activations of chunk cc -> its staged gradient in registers, the bias sums and the head's dW.
-        // (rows past the chunk's end re-read its last entry and count as zero)
-        auto stage = [&](int cc) {
-            int n_e, kc = 0;
-            const float *go_base = grad_out, *out_base = out, *sav_base = saved;
-            int b0 = 0;
-            if constexpr (GRP) {
-                n_e = gp.chunks[cc].z;
-            } else {
-                kc = cc / chunks_per_input, b0 = (cc % chunks_per_input) * FT_CHUNK;
-                n_e = min(FT_CHUNK, d.batch - b0);
-                go_base = grad_out + (size_t)b0 * d.out_ld + (size_t)kc * out_w;
-                out_base = out + (size_t)b0 * d.out_ld + (size_t)kc * out_w;
-                sav_base = saved + ((size_t)kc * d.batch + b0) * d.rows;
-            }
-            float4 r_go[SP], r_a[SP], r_b[SP];
+            for (int pass = 0; pass < decltype(np)::value; pass++)
+                r_eid[pass] = gp.elist[ch.y + min(tg + pass * stride, ch.z - 1)];
+        }
+    };
+    // All loads of a chunk are unconditional (rows past its end re-read its last entry and count as zero when the
+    // gradient is formed): their number is then known to the compiler, and the counted waits stay exact.
+    auto request = [&](auto np, int stride, int tg, float4 *r_go, float4 *r_a, int *r_eid, int cc) {
+        constexpr int NP = decltype(np)::value;
+        if constexpr (GRP) {
 #pragma unroll
-            for (int pass = 0; pass < SP; pass++) {
-                r_go[pass] = r_a[pass] = r_b[pass] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if constexpr (GRP) {
-                    const int e = r_eid[pass];
-                    const int k = e >= d.batch ? 1 : 0, b = e - k * d.batch;
-                    const size_t o_out = (size_t)b * d.out_ld + (size_t)k * out_w + t_col;
-                    if constexpr (FUSED) {
-                        r_go[pass].x = fs.gz[b];
-                        r_go[pass].y = __int_as_float(fs.bucket ? fs.bucket[b] : 0);
-                        r_go[pass].z = __int_as_float(k);
-                    } else {
-                        r_go[pass] = *reinterpret_cast<const float4 *>(grad_out + o_out);
-                    }
-                    if constexpr (PAIR) {
-                        const float *sv = saved + (size_t)e * d.rows + rt * 16 + (s8 & 3) * 4;
-                        r_a[pass] = *reinterpret_cast<const float4 *>(sv);
-                        r_b[pass] = *reinterpret_cast<const float4 *>(sv + half_rows);
-                    } else {
-                        r_a[pass] = *reinterpret_cast<const float4 *>(out + o_out);
-                    }
+            for (int pass = 0; pass < NP; pass++) {
+                const int e = r_eid[pass];
+                const int k = e >= d.batch ? 1 : 0, b = e - k * d.batch;
+                const size_t o_out = (size_t)b * d.out_ld + (size_t)k * out_w + t_col;
+                r_go[pass] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if constexpr (FUSED) {
+                    r_go[pass].x = fs.gz[b];
+                    r_go[pass].y = __int_as_float(fs.bucket ? fs.bucket[b] : 0);
+                    r_go[pass].z = __int_as_float(k);
                 } else {
-                    const uint32_t el = (uint32_t)min(el0 + pass * 32, n_e - 1);
-                    const uint32_t o_out = el * (uint32_t)d.out_ld + t_col;
-                    if constexpr (FUSED) {
-                        r_go[pass].x = fs.gz[b0 + el];
-                        r_go[pass].y = __int_as_float(fs.bucket ? fs.bucket[b0 + el] : 0);
-                    } else {
-                        r_go[pass] = *reinterpret_cast<const float4 *>(go_base + o_out);
-                    }
-                    if constexpr (PAIR) {
-                        const float *sv = sav_base + el * (uint32_t)d.rows + rt * 16 + (s8 & 3) * 4;
-                        r_a[pass] = *reinterpret_cast<const float4 *>(sv);
-                        r_b[pass] = *reinterpret_cast<const float4 *>(sv + half_rows);
-                    } else {
-                        r_a[pass] = *reinterpret_cast<const float4 *>(out_base + o_out);
-                    }
+                    r_go[pass] = *reinterpret_cast<const float4 *>(grad_out + o_out);
                 }
+                if constexpr (PAIR) r_a[pass] = *reinterpret_cast<const float4 *>(saved + (size_t)e * d.rows + sv_col);
+                else r_a[pass] = *reinterpret_cast<const float4 *>(out + o_out);
             }
-            load_eids(cc + 1);  // (GRP) the entry ids of the chunk after this one, for the next call
+            load_eids(np, stride, tg, r_eid, cc + 1);  // the entry ids of the chunk after this one, for the next request
+        } else {
+            // wave-uniform chunk base (SGPRs) + 32-bit per-lane element offsets
+            const int kc = cc / chunks_per_input, b0 = (cc % chunks_per_input) * FT_CHUNK;
+            const int n_e = min(FT_CHUNK, d.batch - b0);
+            const float *go_base = grad_out + (size_t)b0 * d.out_ld + (size_t)kc * out_w;
+            const float *out_base = out + (size_t)b0 * d.out_ld + (size_t)kc * out_w;
+            const float *sav_base = saved + ((size_t)kc * d.batch + b0) * d.rows;
 #pragma unroll
-            for (int pass = 0; pass < SP; pass++) {
-                const int el = el0 + pass * 32;
-                if constexpr (HDW) {
-                    // (whole wave: MFMA runs on all lanes; entries past the chunk's end count with gz = 0)
-                    // A 16-lane row holds the entries 2k (lanes 0-7) and 2k + 1 (lanes 8-15), 8 lanes x float4 each. The
-                    // B operand wants one entry per row (k = lane / 16), so the two halves trade half their float4
-                    // (one DPP rotation by 8 lanes per value): afterwards the row holds entry 2k as 16 x float2 in
-                    // (e0, e1) and entry 2k + 1 in (o0, o1), column 4 * (n & 7) + 2 * (n >> 3) + component for lane n.
-                    const float gzv = el < n_e ? r_go[pass].x : 0.0f;
-                    const int bk = __float_as_int(r_go[pass].y);
-                    const float4 o = r_a[pass];
-                    const float4 pv = make_float4(gzv * o.x, gzv * o.y, gzv * o.z, gzv * o.w);
-                    const bool hi = (threadIdx.x >> 3) & 1;
-                    const float x0 = row_ror8(hi ? pv.x : pv.z), x1 = row_ror8(hi ? pv.y : pv.w);  // from lane ^ 8
-                    const float e0 = hi ? x0 : pv.x, e1 = hi ? x1 : pv.y;
-                    const float o0 = hi ? pv.z : x0, o1 = hi ? pv.w : x1;
-                    const int m = threadIdx.x & 15;
-                    const float a_e = row_share<0>(bk) == m ? 1.0f : 0.0f, a_o = row_share<8>(bk) == m ? 1.0f : 0.0f;
-                    hd[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_e, e0, hd[0], 0, 0, 0);
-                    hd[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_e, e1, hd[1], 0, 0, 0);
-                    hd[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, o0, hd[0], 0, 0, 0);
-                    hd[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, o1, hd[1], 0, 0, 0);
+            for (int pass = 0; pass < NP; pass++) {
+                const uint32_t el = (uint32_t)min(tg + pass * stride, n_e - 1);
+                const uint32_t o_out = el * (uint32_t)d.out_ld + t_col;
+                r_go[pass] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if constexpr (FUSED) {
+                    r_go[pass].x = fs.gz[b0 + el];
+                    r_go[pass].y = __int_as_float(fs.bucket ? fs.bucket[b0 + el] : 0);
+                } else {
+                    r_go[pass] = *reinterpret_cast<const float4 *>(go_base + o_out);
                 }
-                float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (el < n_e) {
-                    float4 go = r_go[pass];
-                    if constexpr (FUSED) {
-                        const float gzv = go.x;
-                        const int bk = __float_as_int(go.y);
-                        const int ke = GRP ? __float_as_int(go.z) : kc;
-                        const float4 wv4 = *reinterpret_cast<const float4 *>(
-                            w1t + (ke * fs.w1_rows + bk) * TW + (PAIR ? (s8 & 3) : s8) * 4);
-                        go = make_float4(gzv * wv4.x, gzv * wv4.y, gzv * wv4.z, gzv * wv4.w);
-                    }
-                    if constexpr (PAIR) {
-                        const float4 own = (s8 < 4) ? r_a[pass] : r_b[pass], oth = (s8 < 4) ? r_b[pass] : r_a[pass];
-                        const float4 dv = bt_act_deriv4(d.act, own);
-                        g = make_float4((go.x * oth.x) * dv.x, (go.y * oth.y) * dv.y, (go.z * oth.z) * dv.z,
-                                        (go.w * oth.w) * dv.w);
-                    } else {
-                        const float4 dv = bt_act_deriv4(d.act, r_a[pass]);
-                        g = make_float4(go.x * dv.x, go.y * dv.y, go.z * dv.z, go.w * dv.w);
-                    }
-                    bsum.x += g.x, bsum.y += g.y, bsum.z += g.z, bsum.w += g.w;
-                }
-                g_reg[pass] = g;
+                if constexpr (PAIR) r_a[pass] = *reinterpret_cast<const float4 *>(sav_base + el * (uint32_t)d.rows + sv_col);
+                else r_a[pass] = *reinterpret_cast<const float4 *>(out_base + o_out);
             }
-        };
-#ifdef BT_OCT_STAGER_PRIO
-        __builtin_amdgcn_s_setprio(BT_OCT_STAGER_PRIO);
-#endif
+        }
+    };
+    auto xor4 = [](float v) {  // the value of lane ^ 4 (two DPP row rotations, each writing its own banks)
+        int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x12C, 0xF, 0x5, false);  // lanes 0-3, 8-11: from lane + 4
+        t = __builtin_amdgcn_update_dpp(t, __float_as_int(v), 0x124, 0xF, 0xA, false);      // lanes 4-7, 12-15: from lane - 4
+        return __int_as_float(t);
+    };
+    // the activations of chunk cc (requested earlier) -> its staged gradient g_out[pass], the bias sums, the head's dW
+    auto form = [&](auto np, int stride, int tg, const float4 *r_go, const float4 *r_a, float4 *g_out, int cc) {
+        constexpr int NP = decltype(np)::value;
+        int n_e, kc = 0;
+        if constexpr (GRP) n_e = gp.chunks[cc].z;
+        else kc = cc / chunks_per_input, n_e = min(FT_CHUNK, d.batch - (cc % chunks_per_input) * FT_CHUNK);
+#pragma unroll
+        for (int pass = 0; pass < NP; pass++) {
+            const int el = tg + pass * stride;
+            if constexpr (HDW) {
+                // (whole wave: MFMA runs on all lanes; entries past the chunk's end count with gz = 0)
+                // A 16-lane row holds the entries 2k (lanes 0-7) and 2k + 1 (lanes 8-15), 8 lanes x float4 each. The
+                // B operand wants one entry per row (k = lane / 16), so the two halves trade half their float4
+                // (one DPP rotation by 8 lanes per value): afterwards the row holds entry 2k as 16 x float2 in
+                // (e0, e1) and entry 2k + 1 in (o0, o1), column 4 * (n & 7) + 2 * (n >> 3) + component for lane n.
+                const float gzv = el < n_e ? r_go[pass].x : 0.0f;
+                const int bk = __float_as_int(r_go[pass].y);
+                const float4 o = r_a[pass];
+                const float4 pv = make_float4(gzv * o.x, gzv * o.y, gzv * o.z, gzv * o.w);
+                const bool hi = (threadIdx.x >> 3) & 1;
+                const float x0 = row_ror8(hi ? pv.x : pv.z), x1 = row_ror8(hi ? pv.y : pv.w);  // from lane ^ 8
+                const float e0 = hi ? x0 : pv.x, e1 = hi ? x1 : pv.y;
+                const float o0 = hi ? pv.z : x0, o1 = hi ? pv.w : x1;
+                const int m = threadIdx.x & 15;
+                const float a_e = row_share<0>(bk) == m ? 1.0f : 0.0f, a_o = row_share<8>(bk) == m ? 1.0f : 0.0f;
+                hd[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_e, e0, hd[0], 0, 0, 0);
+                hd[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_e, e1, hd[1], 0, 0, 0);
+                hd[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, o0, hd[0], 0, 0, 0);
+                hd[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, o1, hd[1], 0, 0, 0);
+            }
+            float4 oth = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if constexpr (PAIR)  // (whole wave: DPP reads the partner lane's registers)
+                oth = make_float4(xor4(r_a[pass].x), xor4(r_a[pass].y), xor4(r_a[pass].z), xor4(r_a[pass].w));
+            float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (el < n_e) {
+                float4 go = r_go[pass];
+                if constexpr (FUSED) {
+                    const float gzv = go.x;
+                    const int bk = __float_as_int(go.y);
+                    const int ke = GRP ? __float_as_int(go.z) : kc;
+                    const float4 wv4 = *reinterpret_cast<const float4 *>(
+                        w1t + (ke * fs.w1_rows + bk) * TW + (PAIR ? (s8 & 3) : s8) * 4);
+                    go = make_float4(gzv * wv4.x, gzv * wv4.y, gzv * wv4.z, gzv * wv4.w);
+                }
+                const float4 dv = bt_act_deriv4(d.act, r_a[pass]);
+                if constexpr (PAIR)
+                    g = make_float4((go.x * oth.x) * dv.x, (go.y * oth.y) * dv.y, (go.z * oth.z) * dv.z,
+                                    (go.w * oth.w) * dv.w);
+                else
+                    g = make_float4(go.x * dv.x, go.y * dv.y, go.z * dv.z, go.w * dv.w);
+                bsum.x += g.x, bsum.y += g.y, bsum.z += g.z, bsum.w += g.w;
+            }
+            g_out[pass] = g;
+        }
+    };
+    // The first chunk is staged by all 16 waves, straight into the tile (nobody reads it yet): a workgroup of a
+    // segment-grouped table has only a handful of chunks, and four waves would take a chunk's time over it.
+    if (c_lo < c_hi) {
+        constexpr int FP = FT_CHUNK / (LDS_THREADS / 8);
+        const std::integral_constant<int, FP> fp;
+        const int tg = threadIdx.x >> 3;
+        float4 f_go[FP], f_a[FP], f_g[FP];
+        int f_eid[FP];
+        load_eids(fp, LDS_THREADS / 8, tg, f_eid, c_lo);
+        request(fp, LDS_THREADS / 8, tg, f_go, f_a, f_eid, c_lo);
+        __syncthreads();  // (the head rows in LDS are complete; c_lo and c_hi are the same for the whole workgroup)
+        form(fp, LDS_THREADS / 8, tg, f_go, f_a, f_g, c_lo);
+#pragma unroll
+        for (int pass = 0; pass < FP; pass++)
+            *reinterpret_cast<float4 *>(gt + (tg + pass * (LDS_THREADS / 8)) * LDS_RT + s8 * 4) = f_g[pass];
+    }
+
+    if (stager) {
+        // ---------------------------------------------------------------- stage: 256 threads, 32 entries per pass
+        // A chunk's activations are requested a whole chunk interval before they are formed (the loads of chunk c + 2 go
+        // out when chunk c + 1 has been formed), so a staging wave never waits for HBM between the two barriers.
+        constexpr int SP = FT_CHUNK / (OCT_STAGERS * 8);
+        constexpr int SS = OCT_STAGERS * 8;
+        const std::integral_constant<int, SP> sp_c;
+        const int el0 = threadIdx.x >> 3;
+        float4 g_reg[SP], r_go[SP], r_a[SP];
+        int r_eid[SP];
         if (c_lo < c_hi) {
-            load_eids(c_lo);
-            stage(c_lo);
+            load_eids(sp_c, SS, el0, r_eid, c_lo + 1);
+            request(sp_c, SS, el0, r_go, r_a, r_eid, min(c_lo + 1, c_hi - 1));
         }
         for (int c = c_lo; c < c_hi; c++) {
             BT_STAMP(0);
             lds_barrier();  // the previous chunk's readers are done with the tile
             BT_STAMP(1);
+            if (c > c_lo) {
 #pragma unroll
-            for (int pass = 0; pass < SP; pass++)
-                *reinterpret_cast<float4 *>(gt + (el0 + pass * 32) * LDS_RT + s8 * 4) = g_reg[pass];
+                for (int pass = 0; pass < SP; pass++)
+                    *reinterpret_cast<float4 *>(gt + (el0 + pass * SS) * LDS_RT + s8 * 4) = g_reg[pass];
+            }
             BT_STAMP(2);
             lds_barrier();
             BT_STAMP(3);
-            if (c + 1 < c_hi) stage(c + 1);
+            if (c + 1 < c_hi) form(sp_c, SS, el0, r_go, r_a, g_reg, c + 1);
+            BT_STAMP(4);
+            // (the last chunks ask for the last one again: unconditional on purpose, see above)
+            request(sp_c, SS, el0, r_go, r_a, r_eid, min(c + 2, c_hi - 1));
             BT_STAMP(5);
         }
     } else {
@@ -1949,29 +1979,35 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
         *reinterpret_cast<float4 *>(pw + (size_t)f * d.stride + d.offset + tile_row(PAIR, rt, half_rows, t8 * 4)) =
             *reinterpret_cast<const float4 *>(acc + f * LDS_RT + t8 * 4);
     }
-    // bias partial: fixed-order sum over the 32 staging thread groups (8 lanes x float4 each)
-    constexpr int SG = OCT_STAGERS * 8;
-    if (stager) *reinterpret_cast<float4 *>(gt + (threadIdx.x >> 3) * LDS_RT + (threadIdx.x & 7) * 4) = bsum;
+    // bias partial: fixed-order sum over the 128 thread groups (8 lanes x float4 each; the reducers' hold the first
+    // chunk's share only), in two levels (8 x 16)
+    *reinterpret_cast<float4 *>(gt + (threadIdx.x >> 3) * LDS_RT + s8 * 4) = bsum;
+    __syncthreads();
+    float bpart = 0.0f;
+    if (threadIdx.x < 8 * LDS_RT) {
+        const int col = threadIdx.x & (LDS_RT - 1), part = threadIdx.x / LDS_RT;
+        for (int i = 0; i < 16; i++) bpart += gt[(part * 16 + i) * LDS_RT + col];
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 * LDS_RT) gt[threadIdx.x] = bpart;
     __syncthreads();
     if (threadIdx.x < LDS_RT) {
         float sb = 0.0f;
-        for (int i = 0; i < SG; i++) sb += gt[i * LDS_RT + threadIdx.x];
+        for (int i = 0; i < 8; i++) sb += gt[i * LDS_RT + threadIdx.x];
         partial_b[(size_t)cg * d.rows + tile_row(PAIR, rt, half_rows, threadIdx.x)] = sb;
     }
     if constexpr (HDW) {
-        // the staging waves' dW1 accumulators -> one partial per (bucket, column) of this tile, the waves in order.
-        // The dW tile has been written out (barriers above), so its LDS holds the OCT_STAGERS x w1_rows x 32 floats.
+        // the waves' dW1 accumulators -> one partial per (bucket, column) of this tile, the waves in order.
+        // The dW tile has been written out (barriers above), so its LDS holds the 16 x w1_rows x 32 floats.
         float *tmp = acc;
         const int lane = threadIdx.x & 63, qd = lane >> 4, j = lane & 15;
         __syncthreads();  // (every thread has read its part of the dW tile)
-        if (stager) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int m = 4 * qd + r;
-                if (m < fs.w1_rows) {
-                    float *t2 = tmp + ((size_t)wv * fs.w1_rows + m) * 32 + 4 * (j & 7) + 2 * (j >> 3);
-                    t2[0] = hd[0][r], t2[1] = hd[1][r];
-                }
+        for (int r = 0; r < 4; r++) {
+            const int m = 4 * qd + r;
+            if (m < fs.w1_rows) {
+                float *t2 = tmp + ((size_t)wv * fs.w1_rows + m) * 32 + 4 * (j & 7) + 2 * (j >> 3);
+                t2[0] = hd[0][r], t2[1] = hd[1][r];
             }
         }
         __syncthreads();
@@ -1979,7 +2015,7 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
         for (int q = threadIdx.x; q < fs.w1_rows * 32; q += LDS_THREADS) {
             const int m = q >> 5, col = q & 31;
             float sh = 0.0f;
-            for (int w2 = 0; w2 < OCT_STAGERS; w2++) sh += tmp[((size_t)w2 * fs.w1_rows + m) * 32 + col];
+            for (int w2 = 0; w2 < LDS_THREADS / 64; w2++) sh += tmp[((size_t)w2 * fs.w1_rows + m) * 32 + col];
             hg.pw1[(size_t)cg * hg.pw1_stride + (size_t)(kk * out_w + rt * 32 + col) * fs.w1_rows + m] = sh;
         }
     }
@@ -2376,7 +2412,7 @@ int ft_plan(const bt_ft_desc *d, FtPlan *p) {
     // (every chunk of a workgroup must belong to one input; the waves' accumulators are merged through the dW tile's LDS)
     p->pw1_stride = (size_t)d->n_inputs * d->rows * FtPlan::kFusedMaxRows;
     p->hdw = p->oct && !p->grouped && !d->pairwise && p->chunks_per_input % p->chunks_per_wg == 0 &&
-             (size_t)p->tc * LDS_RT >= (size_t)OCT_STAGERS * FtPlan::kFusedMaxRows * 64;
+             (size_t)p->tc * LDS_RT >= (size_t)(LDS_THREADS / 64) * FtPlan::kFusedMaxRows * 64;
     if (p->hdw) p->off_pw1 = o, o += bt_align((size_t)p->G * p->pw1_stride * sizeof(float));
     p->total = o;
     return BT_OK;

@@ -41,9 +41,9 @@ for w in range(12):
     rel = (full[:, w, :, :] - t0[:, 0, :, None]).mean(axis=(0, 1))
     print(f"  wave {w + 4:2d}: " + " ".join(f"{rel[i]:7.0f}" for i in (0, 1, 2, 3, 5, 6)))
 sg = st[:, :4, 1:nch - 1, :]
-print("stager timeline: arrive A | leave A | tile written | leave B | next chunk staged")
+print("stager timeline: arrive A | leave A | tile written | leave B | formed | next request sent")
 for w in range(4):
     rel = (sg[:, w, :, :] - t0[:, 0, :, None]).mean(axis=(0, 1))
-    print(f"  wave {w:2d}: " + " ".join(f"{rel[i]:7.0f}" for i in (0, 1, 2, 3, 5)))
+    print(f"  wave {w:2d}: " + " ".join(f"{rel[i]:7.0f}" for i in (0, 1, 2, 3, 4, 5)))
 d = full[..., 5] - full[..., 3]
 print(f"reduce: mean {d.mean():.0f}  fastest wave {d.min(axis=1).mean():.0f}  slowest wave {d.max(axis=1).mean():.0f}")
