@@ -28,14 +28,12 @@ constexpr int FT_CHUNK = 256;  // positions per index chunk (local ids fit u16)
 
 // entries of one chunk's sorted list: every pair plus <= 3 padding ids per feature (runs are 4-aligned)
 __host__ __device__ inline int ft_sorted_cap(int nnz, int cols) { return (FT_CHUNK * nnz + 3 * cols + 7) & ~7; }
-// 4-pair blocks of a chunk's padded list (rounded so LDS arrays behind it stay 16-B aligned)
-__host__ __device__ inline int ft_blk_cap(int nnz, int cols) { return (ft_sorted_cap(nnz, cols) / 4 + 7) & ~7; }
 
 // Test switches, read from the environment when the library is loaded and again only when a test asks for it
 // (bt_internal_reload_env): BT_FT_FORCE_GENERIC=1 runs the any-shape kernels on every shape, BT_FT_FORCE_GROUPED=1
 // the segment-grouped ones wherever a segment is given, BT_FT_FWD_ITEM / BT_FT_BWD_CHUNKS override the item sizes.
 struct FtEnv {
-    bool force_generic = false, force_grouped = false, old_bwd = false;
+    bool force_generic = false, force_grouped = false;
     int fwd_item = 0, bwd_chunks = 0;
     FtEnv() { reload(); }
     void reload() {
@@ -45,7 +43,6 @@ struct FtEnv {
         };
         force_generic = num("BT_FT_FORCE_GENERIC") == 1, force_grouped = num("BT_FT_FORCE_GROUPED") != 0;
         fwd_item = num("BT_FT_FWD_ITEM"), bwd_chunks = num("BT_FT_BWD_CHUNKS");
-        old_bwd = num("BT_FT_OLD_BWD") == 1;  // the range-split reduction (ft_bwd_lds) instead of the octet one
     }
 };
 FtEnv g_ft_env;
@@ -1191,373 +1188,8 @@ struct FtFusedSrc {
     int w1_rows;            // = number of output buckets (one output each)
 };
 
-// GRP (bt_ft_desc.segment): workgroup = (row tile, backward item); the dW tile covers the item's segment of `tc`
-// columns, chunks are slices of the grouped entry list (entry ids two chunks ahead in registers), and the item's
-// slab goes to partial_w[item][tc][stride] for ft_bwd_merge_grp.
-template <bool PAIR, bool FUSED, int NSRT, bool GRP>
-__device__ __forceinline__ void ft_bwd_lds_body(const float *__restrict__ grad_out, const FtFusedSrc &fs,
-                                                const float *__restrict__ out, const float *__restrict__ saved,
-                                                const uint16_t *__restrict__ sorted, const uint32_t *__restrict__ offs,
-                                                float *__restrict__ partial_w, float *__restrict__ partial_b,
-                                                const bt_ft_desc &d, int ntiles, int chunks_per_input,
-                                                int chunks_per_wg, const FtGrp &gp) {
-    extern __shared__ __align__(16) float lds_f[];
-    const int tc = GRP ? gp.tile_cols : d.cols;
-    float *acc = lds_f;                                   // [tc][32]
-    float *gt = acc + (size_t)tc * LDS_RT;                // [FT_CHUNK + 1][32], last row = zeros (padding target)
-    uint16_t *srt = reinterpret_cast<uint16_t *>(gt + (FT_CHUNK + 1) * LDS_RT);    // [ft_sorted_cap]
-    uint16_t *blkf = srt + ft_sorted_cap(d.nnz, tc);                               // [ft_blk_cap] feature of each block
-    int *span = reinterpret_cast<int *>(blkf + ft_blk_cap(d.nnz, tc));             // [4] (2 used): widest run, in groups
-    uint8_t *hrank = reinterpret_cast<uint8_t *>(span + 4);                        // [2][NGRP] rank of a group's head run
-    float *w1t = reinterpret_cast<float *>(hrank + 2 * (LDS_THREADS / 8));          // FUSED: [n_inputs][w1_rows][TW]
-    const int rt = blockIdx.x % ntiles, cg = blockIdx.x / ntiles;
-    const int half_rows = d.rows / 2;
-    const int nchunks = d.n_inputs * chunks_per_input;
-    int g_clo = 0, g_chi = 0;
-    if constexpr (GRP) {
-        if (cg >= gp.counts[1]) return;
-        const int4 it = gp.items[cg];
-        g_clo = it.y, g_chi = it.y + it.z;
-    }
-    const int out_w = PAIR ? half_rows : d.rows;
-    constexpr int TW = PAIR ? 16 : 32;  // output columns per perspective covered by this row tile
-
-    if constexpr (FUSED) {
-        for (int q = threadIdx.x; q < d.n_inputs * fs.w1_rows * TW; q += LDS_THREADS) {
-            const int c = q % TW, bk = (q / TW) % fs.w1_rows, k = q / (TW * fs.w1_rows);
-            w1t[q] = fs.w1[(size_t)(k * out_w + rt * TW + c) * fs.w1_rows + bk];
-        }
-    }
-    for (int q = threadIdx.x; q < tc * LDS_RT; q += LDS_THREADS) acc[q] = 0.0f;
-    if (threadIdx.x < LDS_RT) gt[FT_CHUNK * LDS_RT + threadIdx.x] = 0.0f;
-
-    const int s8 = threadIdx.x & 7, el0 = threadIdx.x >> 3;  // staging role: 128 entries x 8 float4 per pass
-    // reduce role: 128 groups of 8 lanes x float4, two whole rows per ds_read_b128 lane group (fwd_gather_slot)
-    int rg_e, rg_s;
-    fwd_gather_slot(threadIdx.x & 63, rg_e, rg_s);
-    const int grp = (threadIdx.x >> 6) * 8 + rg_e;
-    constexpr int NGRP = LDS_THREADS / 8;
-    if (threadIdx.x < 4) span[threadIdx.x] = 0;
-    if (threadIdx.x < 2 * NGRP) hrank[threadIdx.x] = 0;
-    float4 bsum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const int c_lo = GRP ? g_clo : cg * chunks_per_wg, c_hi = GRP ? g_chi : min(nchunks, c_lo + chunks_per_wg);
-    // Staging registers: the NEXT chunk's global loads are issued before the current chunk's LDS reduction
-    // and consumed after it, so HBM latency overlaps the reduction without a second LDS buffer.
-    constexpr int NPASS = FT_CHUNK / 128;
-    float4 r_go[NPASS], r_a[NPASS], r_b[NPASS];
-    // NSRT: uint4 rounds that cover the sorted list (host-checked)
-    lds_u4_t r_srt[NSRT];  // (clang vector type: an array of HIP's uint4 struct ends up in scratch)
-    uint32_t r_off[2], r_nblk = 0;
-    const int srt_cap = ft_sorted_cap(d.nnz, tc);
-    const int srt_vec = srt_cap / 8;  // uint4 = 8 offsets
-    int r_eid[NPASS], r_ne = 0;  // GRP: entry ids of the NEXT chunk to prefetch; entries of the chunk being staged
-    const uint32_t t_col = PAIR ? rt * 16 + (s8 & 3) * 4 : rt * LDS_RT + s8 * 4;
-    auto load_eids = [&](int c) {
-        if constexpr (GRP) {
-            const int4 ch = gp.chunks[min(c, c_hi - 1)];
-#pragma unroll
-            for (int pass = 0; pass < NPASS; pass++) r_eid[pass] = gp.elist[ch.y + min(el0 + pass * 128, ch.z - 1)];
-        }
-    };
-    // per-thread element offsets inside a chunk (32-bit; the chunk base is wave-uniform and lives in SGPRs)
-    const uint32_t t_out = (uint32_t)el0 * d.out_ld + (PAIR ? rt * 16 + (s8 & 3) * 4 : rt * LDS_RT + s8 * 4);
-    const uint32_t t_sav = (uint32_t)el0 * d.rows + rt * 16 + (s8 & 3) * 4;
-    auto prefetch = [&](int c) {
-        if constexpr (GRP) {
-            const int n_e = gp.chunks[c].z;
-            r_ne = n_e;
-#pragma unroll
-            for (int pass = 0; pass < NPASS; pass++) {
-                const int el = el0 + pass * 128;
-                r_go[pass] = r_a[pass] = r_b[pass] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (el < n_e) {
-                    const int eid = r_eid[pass];
-                    const int k = eid >= d.batch ? 1 : 0, b = eid - k * d.batch;
-                    const size_t o_out = (size_t)b * d.out_ld + (size_t)k * out_w + t_col;
-                    if constexpr (FUSED) {
-                        r_go[pass].x = fs.gz[b];
-                        r_go[pass].y = __int_as_float(fs.bucket ? fs.bucket[b] : 0);
-                        r_go[pass].z = __int_as_float(k);
-                    } else {
-                        r_go[pass] = *reinterpret_cast<const float4 *>(grad_out + o_out);
-                    }
-                    if constexpr (PAIR) {
-                        const float *sv = saved + (size_t)eid * d.rows + rt * 16 + (s8 & 3) * 4;
-                        r_a[pass] = *reinterpret_cast<const float4 *>(sv);
-                        r_b[pass] = *reinterpret_cast<const float4 *>(sv + half_rows);
-                    } else {
-                        r_a[pass] = *reinterpret_cast<const float4 *>(out + o_out);
-                    }
-                }
-            }
-            load_eids(c + 1);
-        }
-        const int k = c / chunks_per_input, cb = c % chunks_per_input;
-        const int b0 = cb * FT_CHUNK;
-        const int n_e = GRP ? 0 : min(FT_CHUNK, d.batch - b0);
-        const float *go_base = grad_out + (size_t)b0 * d.out_ld + (size_t)k * out_w;
-        const float *out_base = out + (size_t)b0 * d.out_ld + (size_t)k * out_w;
-        const float *sav_base = saved + ((size_t)k * d.batch + b0) * d.rows;
-#pragma unroll
-        for (int pass = 0; pass < NPASS; pass++) {
-            const int el = el0 + pass * 128;
-            if constexpr (!GRP) r_go[pass] = r_a[pass] = r_b[pass] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (el < n_e) {
-                if constexpr (FUSED) {
-                    r_go[pass].x = fs.gz[b0 + el];
-                    r_go[pass].y = __int_as_float(fs.bucket ? fs.bucket[b0 + el] : 0);
-                } else {
-                    r_go[pass] = *reinterpret_cast<const float4 *>(go_base + t_out + (uint32_t)pass * 128 * d.out_ld);
-                }
-                if constexpr (PAIR) {
-                    const float *sv = sav_base + t_sav + (uint32_t)pass * 128 * d.rows;
-                    r_a[pass] = *reinterpret_cast<const float4 *>(sv);
-                    r_b[pass] = *reinterpret_cast<const float4 *>(sv + half_rows);
-                } else {
-                    r_a[pass] = *reinterpret_cast<const float4 *>(out_base + t_out + (uint32_t)pass * 128 * d.out_ld);
-                }
-            }
-        }
-        const uint32_t *go_ = offs + (size_t)c * (tc + 1);
-        // thread f keeps the bounds of feature f's run (r_off); features beyond 1024 take a second round below
-        r_off[0] = go_[min((int)threadIdx.x, tc)];
-        r_off[1] = go_[min((int)threadIdx.x + 1, tc)];
-        r_nblk = go_[tc] >> 2;
-        const lds_u4_t *gs = reinterpret_cast<const lds_u4_t *>(sorted + (size_t)c * srt_cap);
-#pragma unroll
-        for (int i = 0; i < NSRT; i++) {
-            const int q = threadIdx.x + i * LDS_THREADS;
-            r_srt[i] = gs[min(q, srt_vec - 1)];
-        }
-    };
-    if (c_lo < c_hi) {
-        load_eids(c_lo);
-        prefetch(c_lo);
-    }
-    for (int c = c_lo; c < c_hi; c++) {
-        const int cb = c % chunks_per_input;
-        const int kc = c / chunks_per_input;
-        const int n_e = GRP ? r_ne : min(FT_CHUNK, d.batch - cb * FT_CHUNK);
-        __syncthreads();  // previous chunk's readers are done with gt / srt / blkf
-#pragma unroll
-        for (int pass = 0; pass < NPASS; pass++) {
-            const int el = el0 + pass * 128;
-            if (el < n_e) {
-                float4 go = r_go[pass];
-                if constexpr (FUSED) {
-                    const float gzv = go.x;
-                    const int bk = __float_as_int(go.y);
-                    const int ke = GRP ? __float_as_int(go.z) : kc;  // the entry's input (perspective)
-                    const float4 wv = *reinterpret_cast<const float4 *>(
-                        w1t + (ke * fs.w1_rows + bk) * TW + (PAIR ? (s8 & 3) : s8) * 4);
-                    go = make_float4(gzv * wv.x, gzv * wv.y, gzv * wv.z, gzv * wv.w);
-                }
-                float4 g;
-                if constexpr (PAIR) {
-                    // lanes s8 < 4 hold rows of the first half (factor c0, partner c1), the others the second half
-                    const float4 own = (s8 < 4) ? r_a[pass] : r_b[pass], oth = (s8 < 4) ? r_b[pass] : r_a[pass];
-                    const float4 dv = bt_act_deriv4(d.act, own);
-                    g = make_float4((go.x * oth.x) * dv.x, (go.y * oth.y) * dv.y, (go.z * oth.z) * dv.z,
-                                    (go.w * oth.w) * dv.w);
-                } else {
-                    const float4 dv = bt_act_deriv4(d.act, r_a[pass]);
-                    g = make_float4(go.x * dv.x, go.y * dv.y, go.z * dv.z, go.w * dv.w);
-                }
-                *reinterpret_cast<float4 *>(gt + el * LDS_RT + s8 * 4) = g;
-                bsum.x += g.x, bsum.y += g.y, bsum.z += g.z, bsum.w += g.w;
-            }
-        }
-        // Work split: the sorted list is a sequence of 4-pair blocks, every block inside one feature's (padded)
-        // run. Group g sums blocks [g*q, (g+1)*q): equal work whatever the feature distribution looks like.
-        const int nblk = (int)r_nblk;
-        const int q = max(1, (nblk + NGRP - 1) / NGRP);
-        const float rcp_q = 1.0f / (float)q;  // block -> group by a float multiply (exact: both < 2^12)
-        int *cur_span = span + (c & 1);
-        uint8_t *cur_rank = hrank + (c & 1) * NGRP;
-        for (int f = threadIdx.x, rnd = 0; f < tc; f += LDS_THREADS, rnd++) {
-            uint32_t o0 = r_off[0], o1 = r_off[1];
-            if (rnd > 0) o0 = offs[(size_t)c * (tc + 1) + f], o1 = offs[(size_t)c * (tc + 1) + f + 1];
-            const int sb = (int)(o0 >> 2), eb = (int)(o1 >> 2);
-            for (int i = sb; i < eb; i++) blkf[i] = (uint16_t)f;
-            if (eb > sb) {
-                // groups g_first+1 .. g_last start inside this run: their first run is a "head" of rank g - g_first
-                const int g_first = (int)(((float)sb + 0.5f) * rcp_q), g_last = (int)(((float)(eb - 1) + 0.5f) * rcp_q);
-                if (g_last > g_first) atomicMax(cur_span, g_last - g_first);
-                for (int g = g_first + 1; g <= g_last; g++) cur_rank[g] = (uint8_t)(g - g_first);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NSRT; i++) {
-            const int qq = threadIdx.x + i * LDS_THREADS;
-            if (qq < srt_vec) reinterpret_cast<lds_u4_t *>(srt)[qq] = r_srt[i];
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) span[(c + 1) & 1] = 0;  // next chunk's counters (their writers come after the next barrier)
-        if (threadIdx.x < NGRP) hrank[((c + 1) & 1) * NGRP + threadIdx.x] = 0;
-        if (c + 1 < c_hi) prefetch(c + 1);
-
-        const int b0 = grp * q, b1 = min(nblk, b0 + q);
-        // A run that began in an earlier group can only be the first one here: its sum is parked in h_part and
-        // added after the groups before it (rank = distance to the group that owns the run's start), so every
-        // feature row of `acc` has one writer at a time and a fixed order of additions.
-        float4 h_part = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        int h_f = 0, h_rank = 0;
-        {
-            const char *gb = reinterpret_cast<const char *>(gt) + rg_s * 16;
-            typedef const volatile __attribute__((address_space(3))) uint64_t *vids_t;
-            typedef const volatile __attribute__((address_space(3))) uint16_t *vblk_t;
-            constexpr uint32_t PAD2 = ((uint32_t)(FT_CHUNK << 7) << 16) | (uint32_t)(FT_CHUNK << 7);  // two zero-row offsets
-            const bool work = b0 < b1;
-            const int last = max(b1 - 1, 0);
-            uint2 w = make_uint2(PAD2, PAD2);
-            int f = 0, fcur = 0;
-            bool headrun = false;
-            if (work) {
-                w = *reinterpret_cast<const uint2 *>(srt + b0 * 4);
-                f = fcur = blkf[b0];
-                h_rank = cur_rank[grp];
-                headrun = h_rank > 0;
-                h_f = f;
-            }
-            float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            // q trips for every group (wave-uniform loop); groups past their range sum the zero row.
-            for (int i = 0; i < q; i++) {
-                // The four waves of a SIMD issue oldest-first, so without this the low wave ids run ahead and the
-                // last ones finish the chunk alone with the LDS half idle. Rotating the issue priority every four
-                // blocks keeps the waves level (-2 % on the step).
-                switch (((i >> 2) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 8)) & 3) {
-                case 0: __builtin_amdgcn_s_setprio(0); break;
-                case 1: __builtin_amdgcn_s_setprio(1); break;
-                case 2: __builtin_amdgcn_s_setprio(2); break;
-                default: __builtin_amdgcn_s_setprio(3); break;
-                }
-                // the next block's offsets / feature are fetched ahead of this block's rows (volatile keeps the
-                // loads in this iteration), and the running row of `acc` is read alongside the gathers, so a block
-                // costs one LDS round trip whether or not a run ends in it
-                const int bn = b0 + i + 1;
-                const bool nact = bn < b1;
-                const int bnc = min(bn, last);
-                const uint64_t wn64 = *(vids_t)(srt + bnc * 4);
-                const int fn_raw = *(vblk_t)(blkf + bnc);
-                const bool chg = f != fcur;
-                float4 *dst = reinterpret_cast<float4 *>(acc + fcur * LDS_RT + rg_s * 4);
-                typedef float lds_f4_t __attribute__((ext_vector_type(4)));
-                // volatile: read with the gathers, not inside the branch below (where it would cost a round trip);
-                // only the groups that end a run here take part (idle 16-lane groups cost no LDS cycle)
-                lds_f4_t old = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (chg) old = *(const volatile __attribute__((address_space(3))) lds_f4_t *)dst;
-                const float4 v0 = *reinterpret_cast<const float4 *>(gb + (w.x & 0xffffu));
-                const float4 v1 = *reinterpret_cast<const float4 *>(gb + (w.x >> 16));
-                const float4 v2 = *reinterpret_cast<const float4 *>(gb + (w.y & 0xffffu));
-                const float4 v3 = *reinterpret_cast<const float4 *>(gb + (w.y >> 16));
-                if (chg) {
-                    if (headrun) {
-                        h_part = a;
-                        headrun = false;
-                    } else {
-                        *dst = make_float4(old.x + a.x, old.y + a.y, old.z + a.z, old.w + a.w);
-                    }
-                    a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    fcur = f;
-                }
-                add4(a, v0), add4(a, v1), add4(a, v2), add4(a, v3);
-                w = nact ? make_uint2((uint32_t)wn64, (uint32_t)(wn64 >> 32)) : make_uint2(PAD2, PAD2);
-                f = nact ? fn_raw : f;
-            }
-            if (work) {
-                if (headrun) {
-                    h_part = a;
-                } else {
-                    float4 *dst = reinterpret_cast<float4 *>(acc + fcur * LDS_RT + rg_s * 4);
-                    float4 cur = *dst;
-                    add4(cur, a);
-                    *dst = cur;
-                }
-            }
-        }
-        const int max_rank = *cur_span;  // written before the barrier above
-        for (int r = 1; r <= max_rank; r++) {
-            __syncthreads();
-            if (h_rank == r) {
-                float4 *dst = reinterpret_cast<float4 *>(acc + h_f * LDS_RT + rg_s * 4);
-                float4 cur = *dst;
-                add4(cur, h_part);
-                *dst = cur;
-            }
-        }
-    }
-    __syncthreads();
-    float *pw = partial_w + (size_t)cg * tc * d.stride;
-    for (int q = threadIdx.x; q < tc * 8; q += LDS_THREADS) {
-        const int f = q >> 3, t8 = q & 7;
-        *reinterpret_cast<float4 *>(pw + (size_t)f * d.stride + d.offset + tile_row(PAIR, rt, half_rows, t8 * 4)) =
-            *reinterpret_cast<const float4 *>(acc + f * LDS_RT + t8 * 4);
-    }
-    // bias partial: fixed-order sum over the 128 staging thread groups, in two levels (8 x 16) so the chain of
-    // dependent LDS reads is 16 + 8 long instead of 128
-    *reinterpret_cast<float4 *>(gt + el0 * LDS_RT + s8 * 4) = bsum;
-    __syncthreads();
-    float bpart = 0.0f;
-    if (threadIdx.x < 8 * LDS_RT) {
-        const int col = threadIdx.x & (LDS_RT - 1), part = threadIdx.x / LDS_RT;
-        for (int i = 0; i < 16; i++) bpart += gt[(part * 16 + i) * LDS_RT + col];
-    }
-    __syncthreads();
-    if (threadIdx.x < 8 * LDS_RT) gt[threadIdx.x] = bpart;
-    __syncthreads();
-    if (threadIdx.x < LDS_RT) {
-        float s = 0.0f;
-        for (int i = 0; i < 8; i++) s += gt[i * LDS_RT + threadIdx.x];
-        partial_b[(size_t)cg * d.rows + tile_row(PAIR, rt, half_rows, threadIdx.x)] = s;
-    }
-}
-
-// Non-pairwise tables whose chunk list fits two staging rounds (Chess768, Ataxx): held to 96 VGPRs, so that four
-// waves per SIMD leave room for one wave of dense_bwd_small_light -- net.hip runs the head's weight-gradient
-// pass next to this kernel.
-template <bool FUSED>
-__global__ __launch_bounds__(LDS_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) void ft_bwd_lds(
-    const float *__restrict__ grad_out, FtFusedSrc fs, const float *__restrict__ out, const float *__restrict__ saved,
-    const uint16_t *__restrict__ sorted, const uint32_t *__restrict__ offs, float *__restrict__ partial_w,
-    float *__restrict__ partial_b, bt_ft_desc d, int ntiles, int chunks_per_input, int chunks_per_wg) {
-    ft_bwd_lds_body<false, FUSED, 2, false>(grad_out, fs, out, saved, sorted, offs, partial_w, partial_b, d, ntiles,
-                                            chunks_per_input, chunks_per_wg, FtGrp{});
-}
-
-template <bool PAIR, bool FUSED, bool GRP>
-__global__ __launch_bounds__(LDS_THREADS) void ft_bwd_lds_any(const float *__restrict__ grad_out, FtFusedSrc fs,
-                                                              const float *__restrict__ out,
-                                                              const float *__restrict__ saved,
-                                                              const uint16_t *__restrict__ sorted,
-                                                              const uint32_t *__restrict__ offs,
-                                                              float *__restrict__ partial_w,
-                                                              float *__restrict__ partial_b, bt_ft_desc d, int ntiles,
-                                                              int chunks_per_input, int chunks_per_wg, FtGrp gp) {
-    ft_bwd_lds_body<PAIR, FUSED, 3, GRP>(grad_out, fs, out, saved, sorted, offs, partial_w, partial_b, d, ntiles,
-                                         chunks_per_input, chunks_per_wg, gp);
-}
-
-// Backward over the octet index (ft_index_oct_kernel): same workgroup shape and staging as ft_bwd_lds_body above --
-// dW tile of 32 rows accumulating in LDS, the activated gradient tile of a chunk staged once -- but the reduction
-// walks per-wave streams: each 8-lane group sums ONE run (or part of a long run) at a time, the eight groups of a
-// wave finish their runs in the same row, and a finished sum is added to its dW row (or parked in its part slot)
-// by one full-wave read-modify-write per eight runs. Parts of cut runs are added to the dW tile in part order after
-// the chunk's barrier. The stream rows come straight from global memory through a register ring two 4-row sets
-// deep; the first two sets of a chunk are peeled so that their waits do not cover the next chunk's staging loads
-// (vmcnt counts in order), which are issued right behind them.
-//
-// HDW (needs FUSED, no PAIR / GRP; every chunk of a workgroup belongs to one input): the head's own weight gradient
-// dW1[bucket[b]][col] += gz[b] * out[b][col] (Matmul::backward dW = dY X^T with one selected row per position,
-// matmul.rs:99-126 + SelectPad, select.rs:93-110) is formed from the `out` tile this kernel stages anyway, so no
-// other kernel re-reads the [B][2H] activations: per staging pass a wave holds 8 entries x 32 columns, exactly the
-// B fragment of v_mfma_f32_16x16x4_f32 (k = entry pair, n = half * 8 + float4 slot); A is the one-hot of the bucket
-// (rows = buckets), the two entries sharing a k take turns through a zeroed half, and the 16 x 16 f32 accumulators
-// (one per float4 component) run through all chunks of the workgroup: an exact-f32 fma chain in a fixed order.
 typedef float oct_f32x4 __attribute__((ext_vector_type(4)));
-// Workgroup barrier for data that travels through LDS only: waits for this wave's LDS operations, not for its global
-// loads. __syncthreads() carries a workgroup-scope fence that drains vmcnt too, which makes a barrier of the chunk
-// loop wait for the loads fetched ahead for the NEXT chunk (stream rows, staging data) -- the latency those
-// prefetches exist to hide. Nothing in this kernel hands global data from one wave to another.
+
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Developer build only (-DBT_STAMPS, tools/stamps_bwd.sh): shader-clock stamps at the phase boundaries of the octet
@@ -2273,7 +1905,7 @@ __global__ __launch_bounds__(256) void ft_bwd_merge(const float *__restrict__ pa
 struct FtPlan {
     bool lds_path;
     int ntiles, G, chunks_per_wg;
-    size_t lds_fwd_bytes, lds_bwd_bytes, off_pw, off_pb;
+    size_t lds_fwd_bytes, off_pw, off_pb;
     static constexpr int kFusedMaxRows = 16;  // head rows (buckets) the fused backward keeps in LDS
     int vec;
     int chunks_per_input, nchunks;
@@ -2318,14 +1950,13 @@ size_t ft_lds_fwd_bytes(const bt_ft_desc *d, int tc, bool grouped) {
     return (size_t)(tc + (grouped ? 2 : 1)) * LDS_RT * sizeof(float) +
            (size_t)(LDS_THREADS / 64) * FWD_EPW * fwd_strip_words((d->nnz + 31) / 32) * sizeof(uint32_t);
 }
-size_t ft_lds_bwd_bytes(const bt_ft_desc *d, int tc) {
-    return ((size_t)tc * LDS_RT + (FT_CHUNK + 1) * LDS_RT) * sizeof(float) +
-           (size_t)ft_sorted_cap(d->nnz, tc) * sizeof(uint16_t) + (size_t)ft_blk_cap(d->nnz, tc) * sizeof(uint16_t) +
-           4 * sizeof(int) + 2 * (LDS_THREADS / 8);
+size_t ft_lds_bwd_bytes(int tc) {  // ft_bwd_oct: gradient tile + zero row, dW tile, part slots (+ the head rows of a fused head)
+    return ((size_t)(FT_CHUNK + 1) * LDS_RT + (size_t)tc * LDS_RT + OCT_SLOTS * LDS_RT) * sizeof(float);
 }
 bool ft_lds_fits(const bt_ft_desc *d, int tc, bool grouped) {
-    return ft_vec(d) == 4 && d->rows % LDS_RT == 0 && ft_lds_bwd_bytes(d, tc) <= 160 * 1024 &&
-           ft_lds_fwd_bytes(d, tc, grouped) <= 160 * 1024 && ft_sorted_cap(d->nnz, tc) / 8 <= 3 * LDS_THREADS;
+    return ft_vec(d) == 4 && d->rows % LDS_RT == 0 && ft_lds_bwd_bytes(tc) <= 160 * 1024 &&
+           ft_lds_fwd_bytes(d, tc, grouped) <= 160 * 1024 && oct_item_cap(tc) <= 1024 &&
+           oct_rows_cap(d->nnz, tc) < 65536 && oct_index_lds_bytes(tc) <= 150 * 1024;
 }
 
 int ft_plan(const bt_ft_desc *d, FtPlan *p) {
@@ -2361,7 +1992,6 @@ int ft_plan(const bt_ft_desc *d, FtPlan *p) {
     o += bt_align((size_t)p->bias_blocks * d->rows * sizeof(float));
     // LDS-resident path: 32-row tiles, table tile + staging must fit the 160 KiB LDS
     p->lds_fwd_bytes = ft_lds_fwd_bytes(d, p->tc, p->grouped);
-    p->lds_bwd_bytes = ft_lds_bwd_bytes(d, p->tc);
     p->lds_path = ft_lds_fits(d, p->tc, p->grouped);
     p->ntiles = d->rows / LDS_RT;
     p->G = 1, p->chunks_per_wg = p->nchunks;
@@ -2401,9 +2031,8 @@ int ft_plan(const bt_ft_desc *d, FtPlan *p) {
         o += bt_align((size_t)p->G * d->rows * sizeof(float));
     }
     p->rows_cap = oct_rows_cap(d->nnz, p->tc);
-    p->lds_oct_bytes = ((size_t)p->tc * LDS_RT + (FT_CHUNK + 1) * LDS_RT + OCT_SLOTS * LDS_RT) * sizeof(float);
-    p->oct = p->lds_path && !g_ft_env.old_bwd && oct_item_cap(p->tc) <= 1024 && p->rows_cap < 65536 &&
-             oct_index_lds_bytes(p->tc) <= 150 * 1024;
+    p->lds_oct_bytes = ft_lds_bwd_bytes(p->tc);
+    p->oct = p->lds_path;  // (the octet index and ft_bwd_oct serve every shape of the LDS path)
     p->off_stream = p->off_meta = p->off_pw1 = 0;
     if (p->oct) {
         p->off_stream = o, o += bt_align((size_t)p->nchunks * p->rows_cap * 8 * sizeof(uint2));
@@ -2442,12 +2071,10 @@ int ft_backward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, 
     float *pw = reinterpret_cast<float *>(ws + p.off_pw), *pb = reinterpret_cast<float *>(ws + p.off_pb);
     dim3 grid(p.ntiles * p.G), block(LDS_THREADS);
     const bool fused = fs.gz != nullptr;
-    const size_t lds = (p.oct ? p.lds_oct_bytes : p.lds_bwd_bytes) +
-                       (fused ? (size_t)d->n_inputs * fs.w1_rows * 32 * sizeof(float) : 0);
-    const bool lean = !p.grouped && !d->pairwise && ft_sorted_cap(d->nnz, d->cols) / 8 <= 2 * LDS_THREADS;
+    const size_t lds = p.lds_oct_bytes + (fused ? (size_t)d->n_inputs * fs.w1_rows * 32 * sizeof(float) : 0);
     const FtGrp gp = ft_grp(p, ws, false);
     const int cpi = p.grouped ? 1 : p.chunks_per_input;
-    if (p.oct) {
+    {
         const uint2 *stream = reinterpret_cast<const uint2 *>(ws + p.off_stream);
         const uint8_t *meta = reinterpret_cast<const uint8_t *>(ws + p.off_meta);
         const FtHeadGradSink hg{head ? reinterpret_cast<float *>(ws + p.off_pw1) : nullptr, p.pw1_stride};
@@ -2476,39 +2103,6 @@ int ft_backward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, 
 #undef BWD_OCT2
 #undef BWD_OCT
     }
-#define BWD_LDS(KERNEL)                                                                                             \
-    do {                                                                                                            \
-        if (int rc = set_lds(KERNEL, lds)) return rc;                                                               \
-        BT_LAUNCH(BTK_FT_BWD_LDS, s, (KERNEL), grid, block, lds, grad_out, fs, out, saved, sorted, offs, pw, pb, *d,  \
-                  p.ntiles, cpi, p.chunks_per_wg);                                                                  \
-    } while (0)
-#define BWD_ANY(KERNEL)                                                                                             \
-    do {                                                                                                            \
-        if (int rc = set_lds(KERNEL, lds)) return rc;                                                               \
-        BT_LAUNCH(BTK_FT_BWD_LDS, s, (KERNEL), grid, block, lds, grad_out, fs, out, saved, sorted, offs, pw, pb, *d,  \
-                  p.ntiles, cpi, p.chunks_per_wg, gp);                                                              \
-    } while (0)
-    if (p.oct) {
-    } else if (lean) {
-        if (fused) BWD_LDS(ft_bwd_lds<true>);
-        else BWD_LDS(ft_bwd_lds<false>);
-    } else if (p.grouped) {
-        if (d->pairwise) {
-            if (fused) BWD_ANY((ft_bwd_lds_any<true, true, true>));
-            else BWD_ANY((ft_bwd_lds_any<true, false, true>));
-        } else {
-            if (fused) BWD_ANY((ft_bwd_lds_any<false, true, true>));
-            else BWD_ANY((ft_bwd_lds_any<false, false, true>));
-        }
-    } else if (d->pairwise) {
-        if (fused) BWD_ANY((ft_bwd_lds_any<true, true, false>));
-        else BWD_ANY((ft_bwd_lds_any<true, false, false>));
-    } else {
-        if (fused) BWD_ANY((ft_bwd_lds_any<false, true, false>));
-        else BWD_ANY((ft_bwd_lds_any<false, false, false>));
-    }
-#undef BWD_LDS
-#undef BWD_ANY
     BT_LAUNCH_CHECK();
     if (d->rows != d->stride) BT_HIP(hipMemsetAsync(dw, 0, (size_t)d->stride * d->cols * sizeof(float), s));
     const long long n = (long long)d->cols * (d->rows / 4) + d->rows;
@@ -2577,7 +2171,7 @@ bool bt_internal_ft_fused_ok(const bt_ft_desc *d, int head_rows) {
     FtPlan p;
     if (ft_validate(d, "ft_fused_ok") || ft_plan(d, &p)) return false;
     return p.lds_path && !force_generic() && head_rows >= 1 && head_rows <= FtPlan::kFusedMaxRows &&
-           (p.oct ? p.lds_oct_bytes : p.lds_bwd_bytes) + (size_t)d->n_inputs * head_rows * 32 * sizeof(float) <= 160 * 1024;
+           p.lds_oct_bytes + (size_t)d->n_inputs * head_rows * 32 * sizeof(float) <= 160 * 1024;
 }
 
 bool bt_internal_ft_fused_head_grad_ok(const bt_ft_desc *d, int head_rows) {
