@@ -57,8 +57,11 @@ static inline int bt_div_up(long long a, long long b) { return (int)((a + b - 1)
 static inline size_t bt_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 // ---- per-kernel HIP-event profiler (bt_profile_* in the C ABI) ----
-// Every kernel launch goes through BT_LAUNCH(id, stream, ...): when profiling is on, a pair of events
-// is recorded on the kernel's own stream around the launch; bt_profile_stop() sums the elapsed times.
+// Every kernel launch goes through BT_LAUNCH(class, stream, kernel, ...): when profiling is on, a pair of events
+// is recorded on the kernel's own stream around the launch; bt_profile_stop() sums the elapsed times per KERNEL,
+// under the kernel's own name with its template arguments, as rocprofv3 prints it (the launch site registers the
+// spelling of its `kernel` argument once: bt_prof_register). The class ids below only pair a completion event with
+// the launch it is meant to ride on (bt_attach_stop_event).
 enum BtKernelId {
     BTK_FT_FWD_GENERIC = 0,
     BTK_FT_FWD_LDS,
@@ -79,6 +82,7 @@ enum BtKernelId {
     BTK_ADAMW,
     BTK_COUNT
 };
+int bt_prof_register(const char *kernel_expr);  // -> profiler id of the kernel spelled `kernel_expr`
 bool bt_prof_enabled(int id);
 void bt_prof_record(int id, hipStream_t s, bool begin);
 struct BtProfScope {
@@ -104,13 +108,14 @@ hipEvent_t bt_take_stop_event(int kernel_id);
 bool bt_prof_take_pair(int id, hipEvent_t *a, hipEvent_t *b);
 #define BT_LAUNCH(id, stream, kernel, grid, block, lds, ...)                                        \
     do {                                                                                            \
+        static const int pk_ = bt_prof_register(#kernel);                                           \
         hipEvent_t stop_ev_ = bt_take_stop_event(id), pa_ = nullptr, pb_ = nullptr;                 \
-        const bool prof_ = bt_prof_enabled(id);                                                     \
-        if (prof_ && bt_prof_take_pair(id, &pa_, &pb_)) {                                           \
+        const bool prof_ = bt_prof_enabled(pk_);                                                    \
+        if (prof_ && bt_prof_take_pair(pk_, &pa_, &pb_)) {                                          \
             hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, pa_, pb_, 0, __VA_ARGS__);      \
             if (stop_ev_) (void)hipEventRecord(stop_ev_, stream); /* timed: the completion event gets its own packet */ \
         } else {                                                                                    \
-            BtProfScope prof_scope_(id, stream, prof_);                                             \
+            BtProfScope prof_scope_(pk_, stream, prof_);                                            \
             if (stop_ev_)                                                                           \
                 hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, stop_ev_, 0, __VA_ARGS__); \
             else                                                                                    \

@@ -3,6 +3,8 @@
 // ROCm implementation crates/gpu/src/runtime/rocm.rs:66-171), straight on the HIP runtime.
 #include <cstring>
 #include <string>
+#include <mutex>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -29,20 +31,53 @@ struct Profiler {
     size_t used = 0;
     std::vector<ProfRec> recs;
     hipEvent_t pending = nullptr;
-    unsigned long long filter = ~0ull;  // bit i set = kernel id i is timed
-    int every = 1;                      // time every n-th launch of a kernel id (bt_profile_set_sampling)
-    unsigned seen[BTK_COUNT] = {0};
+    unsigned long long filter = ~0ull;  // bit i set = kernel id i < 64 is timed (bt_profile_set_filter)
+    std::vector<std::string> only;      // if not empty: only kernels whose name contains one of these (bt_profile_only)
+    int every = 1;                      // time every n-th launch of a kernel (bt_profile_set_sampling)
+    std::vector<unsigned> seen;
+    std::vector<signed char> allowed;   // per kernel id: -1 unknown, 0 filtered out, 1 timed
 };
 thread_local Profiler g_prof;
-const char *const kKernelNames[BTK_COUNT] = {
-    "ft_fwd_generic", "ft_fwd_lds", "ft_index_kernel", "ft_bwd_make_g", "ft_bwd_gather", "ft_bwd_lds",
-    "ft_bwd_merge", "colsum_partial", "colsum_final", "dense_fwd_kernel", "dense_fwd_small", "dense_bwd_small", "dense_bwd_dx_kernel",
-    "dense_bwd_dw_kernel", "sum_partials_kernel", "sigmoid_mse_kernel", "adamw_kernel"};
+// kernel names in registration order (a launch site registers once, on its first launch, from any thread)
+std::mutex g_names_mutex;
+std::vector<std::string> &kernel_names() {
+    static std::vector<std::string> names;
+    return names;
+}
+std::string kernel_name(int id) {
+    std::lock_guard<std::mutex> lock(g_names_mutex);
+    return (id >= 0 && id < (int)kernel_names().size()) ? kernel_names()[id] : std::string();
+}
 }  // namespace
+
+int bt_prof_register(const char *kernel_expr) {
+    // the spelling of BT_LAUNCH's kernel argument -> "name<args>" as rocprofv3 prints it: no outer parentheses,
+    // ", " between template arguments
+    std::string n;
+    for (const char *c = kernel_expr; *c; c++)
+        if (*c != ' ' && *c != '(' && *c != ')') n += *c, n += (*c == ',' ? " " : "");
+    std::lock_guard<std::mutex> lock(g_names_mutex);
+    auto &names = kernel_names();
+    for (size_t i = 0; i < names.size(); i++)
+        if (names[i] == n) return (int)i;
+    names.push_back(n);
+    return (int)names.size() - 1;
+}
 
 bool bt_prof_enabled(int id) {
     Profiler &p = g_prof;
-    if (!p.on || !((p.filter >> id) & 1ull)) return false;
+    if (!p.on) return false;
+    if ((size_t)id >= p.seen.size()) p.seen.resize(id + 1, 0u), p.allowed.resize(id + 1, (signed char)-1);
+    if (p.allowed[id] < 0) {
+        bool ok = id >= 64 || ((p.filter >> id) & 1ull);
+        if (ok && !p.only.empty()) {
+            const std::string n = kernel_name(id);
+            ok = false;
+            for (const std::string &w : p.only) ok = ok || n.find(w) != std::string::npos;
+        }
+        p.allowed[id] = ok ? 1 : 0;
+    }
+    if (!p.allowed[id]) return false;
     return (p.seen[id]++ % (unsigned)p.every) == 0;
 }
 
@@ -95,8 +130,9 @@ int bt_profile_start(int max_launches) {
     p.recs.clear();
     p.pending = nullptr;
     p.filter = ~0ull;
+    p.only.clear();
     p.every = 1;
-    for (unsigned &s : p.seen) s = 0;
+    p.seen.clear(), p.allowed.clear();
     p.on = true;
     return BT_OK;
 }
@@ -109,13 +145,22 @@ int bt_profile_set_sampling(int every) {
 
 int bt_profile_set_filter(unsigned long long kernel_mask) {
     g_prof.filter = kernel_mask;
+    g_prof.allowed.assign(g_prof.allowed.size(), (signed char)-1);
+    return BT_OK;
+}
+
+int bt_profile_only(const char *name_part) {
+    BT_REQUIRE(name_part && name_part[0], "bt_profile_only: empty name");
+    g_prof.only.push_back(name_part);
+    g_prof.allowed.assign(g_prof.allowed.size(), (signed char)-1);
     return BT_OK;
 }
 
 int bt_profile_stop(int *counts, double *total_ms, int n_ids) {
     Profiler &p = g_prof;
     p.on = false;
-    BT_REQUIRE(counts && total_ms && n_ids >= BTK_COUNT, "bt_profile_stop: need arrays of bt_profile_num_kernels() entries");
+    BT_REQUIRE(counts && total_ms && n_ids >= bt_profile_num_kernels(),
+               "bt_profile_stop: need arrays of bt_profile_num_kernels() entries");
     for (int i = 0; i < n_ids; i++) counts[i] = 0, total_ms[i] = 0.0;
     for (const ProfRec &r : p.recs) {
         BT_HIP(hipEventSynchronize(r.b));
@@ -129,9 +174,15 @@ int bt_profile_stop(int *counts, double *total_ms, int n_ids) {
     return BT_OK;
 }
 
-int bt_profile_num_kernels(void) { return BTK_COUNT; }
+int bt_profile_num_kernels(void) {
+    std::lock_guard<std::mutex> lock(g_names_mutex);
+    return (int)kernel_names().size();
+}
 
-const char *bt_profile_kernel_name(int id) { return (id >= 0 && id < BTK_COUNT) ? kKernelNames[id] : ""; }
+const char *bt_profile_kernel_name(int id) {  // (valid until the library is unloaded: names are never removed)
+    std::lock_guard<std::mutex> lock(g_names_mutex);
+    return (id >= 0 && id < (int)kernel_names().size()) ? kernel_names()[id].c_str() : "";
+}
 
 int bt_version(void) { return 1; }
 

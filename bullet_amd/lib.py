@@ -143,7 +143,7 @@ SYMBOLS = [
     "bt_host_alloc_pinned", "bt_host_free_pinned", "bt_stream_create", "bt_stream_destroy", "bt_stream_sync",
     "bt_event_create", "bt_event_destroy", "bt_event_record", "bt_stream_wait_event", "bt_event_sync", "bt_event_query",
     "bt_memset_async", "bt_memcpy_h2d_async", "bt_memcpy_d2h_async", "bt_memcpy_d2d_async",
-    "bt_profile_start", "bt_profile_set_filter", "bt_profile_set_sampling", "bt_profile_stop", "bt_profile_num_kernels", "bt_profile_kernel_name",
+    "bt_profile_start", "bt_profile_set_filter", "bt_profile_only", "bt_profile_set_sampling", "bt_profile_stop", "bt_profile_num_kernels", "bt_profile_kernel_name",
     "bt_ft_forward", "bt_ft_backward_workspace_bytes", "bt_ft_backward", "bt_ft_build_index",
     "bt_ft_backward_prebuilt", "bt_ft_forward_prebuilt", "bt_ft_segment_violations",
     "bt_dense_forward", "bt_dense_backward_workspace_bytes", "bt_dense_backward", "bt_dense_backward_static",
@@ -295,17 +295,13 @@ def check(rc):
 
 
 def profile_start(max_launches=100000, only=None, every=1):
-    """only: iterable of kernel names to time (None = all); every: time every n-th launch of each"""
+    """only: iterable of kernel names (or parts of names) to time (None = all); every: time every n-th launch of each"""
     L = load()
     check(L.bt_profile_start(max_launches))
     if every > 1:
         check(L.bt_profile_set_sampling(every))
-    if only is not None:
-        names = {L.bt_profile_kernel_name(i).decode(): i for i in range(L.bt_profile_num_kernels())}
-        mask = 0
-        for n in only:
-            mask |= 1 << names[n]
-        check(L.bt_profile_set_filter(mask))
+    for n in only or ():
+        check(L.bt_profile_only(n.encode()))
 
 
 def profile_stop():

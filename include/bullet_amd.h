@@ -90,8 +90,12 @@ int bt_memcpy_d2d_async(void *dst, const void *src, size_t bytes, void *stream);
  * calling thread's profiler for up to max_launches kernel launches; bt_profile_stop waits for the
  * events and fills counts[id] / total_ms[id] for id < bt_profile_num_kernels(). */
 int bt_profile_start(int max_launches);
-/* restrict timing to the kernels whose id bit is set (after bt_profile_start); default all */
+/* restrict timing to the kernels whose id bit is set (ids < 64; after bt_profile_start); default all */
 int bt_profile_set_filter(unsigned long long kernel_mask);
+/* restrict timing to kernels whose name contains `name_part` (after bt_profile_start; calls add up). Kernels are
+ * reported under their own names with template arguments, as rocprofv3 --kernel-trace prints them (e.g.
+ * "ft_bwd_oct<false, true, false, true>"); an id is assigned at a kernel's first launch. */
+int bt_profile_only(const char *name_part);
 /* time only every n-th launch of each selected kernel (after bt_profile_start; default 1): a timed launch carries
  * profiling timestamps on its dispatch packet, which costs the stream ~10 us, so a caller that wants an average
  * over a run without slowing it samples */

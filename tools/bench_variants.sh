@@ -10,6 +10,6 @@ for name in real "$@"; do
 import sys, json
 d = json.loads(sys.stdin.read())
 k = d.get('kernels_us_per_step_warmup', {})
-print('$name $occ', round(d['value'] / 1e6, 2), 'M pos/s', round(d['ms_per_step'], 4), 'ms', 'bwd', round(d.get('roofline', {}).get('avg_launch_us', 0), 1), 'fwd', k.get('ft_fwd_lds'), 'idx', k.get('ft_index_kernel'))"
+print('$name $occ', round(d['value'] / 1e6, 2), 'M pos/s', round(d['ms_per_step'], 4), 'ms', 'bwd', round(d.get('roofline', {}).get('avg_launch_us', 0), 1), 'fwd', next((v for n, v in k.items() if n.startswith('ft_fwd_lds')), None), 'idx', next((v for n, v in k.items() if n.startswith('ft_index')), None))"
   done
 done

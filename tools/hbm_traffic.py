@@ -10,14 +10,11 @@ import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_hbm"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/hbm_traffic.json"
-# real kernel name -> the id bench.py's live HIP-event table files it under (when they differ)
-BENCH_ID = {"ft_bwd_oct": "ft_bwd_lds", "ft_index_oct_kernel": "ft_index_kernel", "ft_bwd_merge_head": "ft_bwd_merge",
-            "ft_bwd_lds_any": "ft_bwd_lds", "ft_bwd_merge_grp": "ft_bwd_merge"}
 KERNELS = ["ft_fwd_lds", "ft_index_kernel", "ft_index_oct_kernel", "ft_bwd_oct", "ft_bwd_merge_head", "map_batch_kernel",
-           "ft_bwd_lds", "ft_bwd_merge", "head_finish_kernel", "dense_fwd_small",
+           "ft_bwd_merge", "head_finish_kernel", "dense_fwd_small",
            "dense_bwd_small_light", "dense_bwd_small", "sum_partials_seq4_kernel", "sum_partials4_kernel", "adamw_kernel",
            # the HalfKA multi-layer nets (bench.py --net cfg3 / cfg4)
-           "ft_bwd_lds_any", "ft_bwd_merge_grp", "ft_group_count", "ft_group_place", "bucket_count_kernel", "bucket_place_kernel", "ft_bwd_merge_step",
+           "ft_bwd_merge_grp", "ft_group_count", "ft_group_place", "bucket_count_kernel", "bucket_place_kernel", "ft_bwd_merge_step",
            "dense_mfma_fwd", "dense_mfma_dx", "dense_mfma_dw", "dense_mfma_sum", "dense_tail_kernel", "dense_tail_sum",
            "dense_gz_kernel", "factor_expand_kernel", "factor_reduce_kernel"]
 
@@ -43,7 +40,7 @@ for k in KERNELS:
         per_launch = (2 * f[k] + w[k]) * 1024
         lps = nf[k] / steps
         lps = float(round(lps)) if abs(lps - round(lps)) < 0.2 and round(lps) >= 1 else lps  # (+1 launch: the first upload)
-        out[k] = {"kernel": k, "bench_id": BENCH_ID.get(k, k), "FETCH_SIZE_KB": round(f[k], 1), "WRITE_SIZE_KB": round(w[k], 1),
+        out[k] = {"kernel": k, "FETCH_SIZE_KB": round(f[k], 1), "WRITE_SIZE_KB": round(w[k], 1),
                   "hbm_bytes_per_launch": round(per_launch, 1), "launches_per_step": round(lps, 3)}
         total += per_launch * lps
 # uploads of the next batch are copies, not kernels: B * (2 N + 3) * 4 bytes written per step, not in the counters
