@@ -124,6 +124,15 @@ int bt_comm_from_hooks(const bt_comm_hooks *hooks, int rank, int world, bt_comm 
     return BT_OK;
 }
 
+int bt_comm_use_own_stream(bt_comm *c) {
+    BT_REQUIRE(c, "bt_comm_use_own_stream: null communicator");
+    if (c->stream) return BT_OK;  // (a native RCCL communicator has one from the start)
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    for (auto &e : c->ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    BT_REQUIRE(ok, "bt_comm_use_own_stream: could not create the collective stream / events");
+    return BT_OK;
+}
+
 int bt_comm_destroy(bt_comm *c) {
     if (!c) return BT_OK;
     if (c->stream) (void)hipStreamSynchronize(c->stream);

@@ -85,7 +85,7 @@ class Comm:
         return cls(h, rank, world)
 
     @classmethod
-    def from_torch(cls, dist):
+    def from_torch(cls, dist, own_stream=False):
         import ctypes as C
         import torch
         from . import lib
@@ -137,6 +137,8 @@ class Comm:
                               lib.COMM_SCATTER_CB(guarded(all_gather)), None)
         h = C.c_void_p()
         lib.check(L.bt_comm_from_hooks(C.byref(hooks), rank, world, C.byref(h)))
+        if own_stream:  # the hooks then run on the communicator's stream, event-fenced against the step's (bt_net_dp_step)
+            lib.check(L.bt_comm_use_own_stream(h))
         self.h, self._keep = h, (hooks,)
         return self
 

@@ -639,6 +639,11 @@ typedef struct {
     void *user;
 } bt_comm_hooks;
 int bt_comm_from_hooks(const bt_comm_hooks *hooks, int rank, int world, bt_comm **comm);
+/* Gives a hook communicator a collective stream of its own, as a native RCCL communicator has from the start:
+ * bt_net_dp_step then calls the hooks with THAT stream and fences it against the step's stream with events (the
+ * table's reduce-scatter runs beside the optimiser step of the other tensors). For collective libraries that want
+ * their own stream; no counterpart in the reference (it has no multi-device path). */
+int bt_comm_use_own_stream(bt_comm *comm);
 int bt_comm_destroy(bt_comm *comm);
 int bt_comm_rank(const bt_comm *comm);
 int bt_comm_world(const bt_comm *comm);

@@ -29,11 +29,13 @@ BATCH, BPS, SBS = 1001, 3, 2  # odd batch: uneven shards
 
 def _run(dist, device_mapper, kind="single", mode="dist", comm=None):
     """mode "dist": the grad_sync hook over torch.distributed; "comm" / "sharded": a bt_comm (bt_net_dp_step), the
-    second with the table forced onto the sharded path (reduce-scatter, optimiser on the own slice, all-gather)"""
+    second with the table forced onto the sharded path (reduce-scatter, optimiser on the own slice, all-gather);
+    "sharded_own": the same with the collectives on a stream of the communicator's own (bt_comm_use_own_stream), i.e.
+    the event-fenced sequence a native RCCL communicator takes, here with real summation between two ranks"""
     from bullet_amd import lib, parallel
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
     if dist is not None and mode != "dist":
-        comm, dist = parallel.Comm.from_torch(dist), None
+        comm, dist = parallel.Comm.from_torch(dist, own_stream=mode == "sharded_own"), None
     lo, hi = parallel.shard_range(BATCH, rank, world)
     multi = kind == "multi"
     net = lib.Net(lib.make_net_desc(**(CFG_MULTI if multi else CFG)), hi - lo)
@@ -43,9 +45,9 @@ def _run(dist, device_mapper, kind="single", mode="dist", comm=None):
     rep = net.train(idesc, [GOLDEN], BATCH, BPS, SBS,
                     lib.LrSched(lib.LR["constant"], 0.001, 0, 0, 0), lib.WdlSched(lib.WDL["constant"], 0.3, 0, 0),
                     out_buckets=8, threads=2, on_batch=lambda sb, b, l: losses.append(l),
-                    device_mapper=device_mapper, dist=dist, comm=comm, shard_min_floats=1024 if mode == "sharded" else 0)
+                    device_mapper=device_mapper, dist=dist, comm=comm, shard_min_floats=1024 if mode.startswith("sharded") else 0)
     params = net.params.detach().cpu().numpy().copy()
-    if mode == "sharded":  # the optimiser state was gathered before bt_train_run returned: part of the comparison
+    if mode.startswith("sharded"):  # the optimiser state was gathered before bt_train_run returned: part of the comparison
         n = net.n_flat
         state = [parallel.device_view(f(net.h), n).cpu().numpy().copy() for f in (net.L.bt_net_momentum, net.L.bt_net_velocity)]
         params = np.concatenate([params] + state)
@@ -72,7 +74,8 @@ def _worker(rank, world, port, device_mapper, q, kind="single", mode="dist"):
 
 @pytest.mark.parametrize("device_mapper,kind,mode", [(False, "single", "dist"), (True, "single", "dist"),
                                                      (True, "multi", "dist"), (True, "single", "comm"),
-                                                     (False, "single", "sharded"), (True, "multi", "sharded")])
+                                                     (False, "single", "sharded"), (True, "multi", "sharded"),
+                                                     (True, "single", "sharded_own"), (True, "multi", "sharded_own")])
 def test_two_rank_train_run_matches_single_process(device_mapper, kind, mode):
     import torch.multiprocessing as mp
     s = socket.socket()
