@@ -445,10 +445,11 @@ def main():
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            try:
+            try:  # (Comm.rccl has every rank agree that librccl loads before any of them enters ncclCommInitRank; an init
+                # failure after that agreement cannot be recovered from collectively and ends the job)
                 comm = parallel.Comm.rccl(dist)
                 comm_kind = "native RCCL communicator (bt_comm_init_rank)"
-            except Exception as e:  # the same collectives through torch.distributed's RCCL, as hooks: slower host path
+            except RuntimeError as e:  # the same collectives through torch.distributed's RCCL, as hooks: slower host path
                 print(f"rank {rank}: native communicator unavailable ({e}); falling back to torch.distributed hooks",
                       file=sys.stderr)
                 comm = parallel.Comm.from_torch(dist)

@@ -124,6 +124,8 @@ int bt_comm_from_hooks(const bt_comm_hooks *hooks, int rank, int world, bt_comm 
     return BT_OK;
 }
 
+int bt_comm_available(void) { return rccl_load() == BT_OK ? 1 : 0; }
+
 int bt_comm_use_own_stream(bt_comm *c) {
     BT_REQUIRE(c, "bt_comm_use_own_stream: null communicator");
     if (c->stream) return BT_OK;  // (a native RCCL communicator has one from the start)

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(MAP_WAVES * 64) void map_batch_kernel(bt_input_desc
         }
         if (d.factorised) cnt *= 2;
     }
-    bad |= result > 2;  // value.rs:101 indexes targets[result]
+    bad |= result > 2;  // value.rs:101 (WDL: a panic); scalar targets too, on purpose (stricter than value.rs:112, see bullet_amd.h)
     if (lane != 0) return;
     if (bad) {
         atomicAdd(&g_map_errors, 1);

@@ -724,8 +724,10 @@ __global__ __launch_bounds__(OCT_IDX_THREADS, 6) void ft_index_oct_kernel(const 
         const int j = jraw - col0;
         const bool active = (e < e_hi) && (li < nvalid) && in_seg(j);
         uint32_t i = 0;
-        for (int q = 0; q < eps; q++)
+        for (int q = 0; q < eps; q++) {
             if (active && sub == q) i = atomicAdd(&start[j], (e & 1) ? 0x10000u : 1u);
+            __builtin_amdgcn_wave_barrier();  // one entry after the other: the iterations are not to be merged
+        }
         if (active) {
             // rank inside the run: the group's preferred parity first (the group = the sorted position of the run's first item)
             const uint32_t tp = tpar[j], odd = (uint32_t)e & 1u, pref = (uint32_t)ipos[item0[j]] & 1u;

@@ -158,7 +158,9 @@ void map_range(const bt_input_desc *d, const bt_map_opts *o, const uint8_t *reco
             }
             bucket = (uint8_t)((uint8_t)pieces - 2) / (uint8_t)divisor;
         }
-        if (result > 2) {  // value.rs:101 indexes targets[result]; value.rs:112 would form a target outside [0, 1]
+        // WDL targets: value.rs:101 indexes targets[result] (a panic). Scalar targets: the reference keeps training with
+        // result / 2 > 1 (value.rs:112); rejected here too, on purpose (stricter than the reference, corrupt data only)
+        if (result > 2) {
             reject(REC_RESULT);
             continue;
         }

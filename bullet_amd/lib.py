@@ -143,7 +143,7 @@ SYMBOLS = [
     "bt_host_alloc_pinned", "bt_host_free_pinned", "bt_stream_create", "bt_stream_destroy", "bt_stream_sync",
     "bt_event_create", "bt_event_destroy", "bt_event_record", "bt_stream_wait_event", "bt_event_sync", "bt_event_query",
     "bt_memset_async", "bt_memcpy_h2d_async", "bt_memcpy_d2h_async", "bt_memcpy_d2d_async",
-    "bt_comm_use_own_stream", "bt_profile_start", "bt_profile_set_filter", "bt_profile_only", "bt_profile_set_sampling", "bt_profile_stop", "bt_profile_num_kernels", "bt_profile_kernel_name",
+    "bt_comm_use_own_stream", "bt_comm_available", "bt_profile_start", "bt_profile_set_filter", "bt_profile_only", "bt_profile_set_sampling", "bt_profile_stop", "bt_profile_num_kernels", "bt_profile_kernel_name",
     "bt_ft_forward", "bt_ft_backward_workspace_bytes", "bt_ft_backward", "bt_ft_build_index",
     "bt_ft_backward_prebuilt", "bt_ft_forward_prebuilt", "bt_ft_segment_violations",
     "bt_dense_forward", "bt_dense_backward_workspace_bytes", "bt_dense_backward", "bt_dense_backward_static",

@@ -65,6 +65,15 @@ class Comm:
         from . import lib
         L = lib.load()
         rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+        # every rank says whether it can load librccl BEFORE anyone enters ncclCommInitRank, which blocks until all
+        # ranks have joined: one rank without the library would otherwise leave the others waiting there
+        ok = bool(L.bt_comm_available())
+        if world > 1:
+            flags = [None] * world
+            dist.all_gather_object(flags, ok)
+            ok = all(flags)
+        if not ok:
+            raise RuntimeError("the native RCCL communicator is not available on every rank: " + L.bt_last_error().decode())
         ident = C.create_string_buffer(128)
         payload, err = None, None
         if rank == 0:
@@ -81,7 +90,10 @@ class Comm:
             raise err or RuntimeError("rank 0 could not create the RCCL unique id")
         ident = C.create_string_buffer(payload, 128)
         h = C.c_void_p()
-        lib.check(L.bt_comm_init_rank(ident, rank, world, C.byref(h)))
+        try:
+            lib.check(L.bt_comm_init_rank(ident, rank, world, C.byref(h)))
+        except lib.BtError as e:  # the other ranks are inside ncclCommInitRank: no collective fallback from here
+            raise SystemExit(f"rank {rank}: bt_comm_init_rank failed after every rank had agreed to use RCCL: {e}")
         return cls(h, rank, world)
 
     @classmethod

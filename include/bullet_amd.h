@@ -437,8 +437,10 @@ int bt_chessboard_from_str(const char *line, void *record32);
 int bt_map_batch_device(void *stream, const bt_input_desc *d, const bt_map_opts *o, const void *records_dev, int count,
                         int32_t *stm, int32_t *nstm, int32_t *buckets, float *targets, float *weights);
 /* A record the reference's mapper would panic on (more than 32 pieces, piece types 6 / 7, king squares > 63, result
- * > 2, fewer than two pieces with output buckets: value.rs:80,91,101, chess_buckets.rs:30, outputs.rs:29) makes
- * bt_map_batch fail with BT_ERR_INVALID ("bt_map_batch: record <i>: <reason>"). The device mapper cannot fail a call
+ * > 2 with WDL targets, fewer than two pieces with output buckets: value.rs:80,91,101, chess_buckets.rs:30,
+ * outputs.rs:29) makes bt_map_batch fail with BT_ERR_INVALID ("bt_map_batch: record <i>: <reason>"). One deliberate,
+ * stricter divergence: a result > 2 is rejected with scalar targets as well, where the reference would go on
+ * training with the target blend * result / 2 > 1 (value.rs:112); it only shows on corrupt data. The device mapper cannot fail a call
  * it has only enqueued: it maps such a record to an empty list with zero weight and counts it; this call waits for
  * `stream`, returns the count since the last call on the current device and clears it. bt_train_run checks it after
  * every superbatch and fails with BT_ERR_INVALID when it is non-zero. */
@@ -639,6 +641,10 @@ typedef struct {
     void *user;
 } bt_comm_hooks;
 int bt_comm_from_hooks(const bt_comm_hooks *hooks, int rank, int world, bt_comm **comm);
+/* 1 if librccl and every symbol the native communicator binds can be loaded in this process, else 0 (the reason is in
+ * bt_last_error()). Launchers ask every rank BEFORE bt_comm_init_rank, which blocks until all ranks have joined: a rank
+ * that cannot load the library would otherwise leave the others waiting inside ncclCommInitRank. */
+int bt_comm_available(void);
 /* Gives a hook communicator a collective stream of its own, as a native RCCL communicator has from the start:
  * bt_net_dp_step then calls the hooks with THAT stream and fences it against the step's stream with events (the
  * table's reduce-scatter runs beside the optimiser step of the other tensors). For collective libraries that want

@@ -47,7 +47,7 @@ def test_oracle_reproduces_reference_printed_loss(hidden, expected):
 TEST2_LAYOUT = [0, 0, 0, 0] + [1] * 28  # examples/tests/test2.rs:16-25
 
 
-def test2_net():
+def net_of_test2():
     # test2.rs:39-65: l0f [128 x 768] repeated over 2 input buckets; CReLU pairwise FT; l1 -> 8x16 select,
     # row 15 = skip neuron, rows 0..14 -> concat(x, x*x).crelu(); l2 -> 8x32 select screlu; l3 -> 8 select; + skip
     return ob.make_net(768 * 2, 32, 128, "crelu",
@@ -58,7 +58,7 @@ def test2_net():
 def run_test2_schedule(steps=10, batch=16384):
     rec = np.fromfile(GOLDEN, dtype=np.uint8).reshape(-1, 32)
     n = rec.shape[0]
-    d = test2_net()
+    d = net_of_test2()
     params = ob.net_init(d)
     m = [np.zeros_like(p) for p in params]
     v = [np.zeros_like(p) for p in params]
