@@ -55,7 +55,7 @@ struct bt_net {
     bool primed = false;
     bt_batch primed_key = {};
     hipEvent_t ev_step = nullptr;
-    hipEvent_t next_ready = nullptr, ev_next = nullptr;
+    hipEvent_t next_ready = nullptr, ev_next = nullptr, ev_next_groups = nullptr;
 };
 
 namespace {
@@ -240,7 +240,7 @@ struct PermScope {
 // fwd_event: record ev_fwd when the forward pass is complete (the side-stream head backward waits for it)
 int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bool want_gz0 = false,
                  bool head_in_ft = false, bool groups_ready = false, bool perm_on_side = false, int n_layers = -1,
-                 bool fwd_event = true) {
+                 bool fwd_event = true, hipEvent_t join_layers = nullptr) {
     bt_ft_desc f = ft_desc(n, b->batch);
     const int32_t *idx[2] = {b->stm, b->nstm};
     const float *w0 = nullptr;
@@ -274,6 +274,7 @@ int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bo
         return rc;
     const float *x = n->hid;
     if (perm_on_side) BT_HIP(hipStreamWaitEvent(s, n->ev_index, 0));
+    if (join_layers) BT_HIP(hipStreamWaitEvent(s, join_layers, 0));  // a batch prepared ahead: its bucket order and sorted index
     if (n_layers < 0) n_layers = n->d.n_dense;
     for (int k = 0; k < n_layers; k++) {
         bt_dense_desc q = dn_desc(n, k, b->batch);
@@ -321,7 +322,13 @@ int prepare_next(bt_net *n, bool side_behind) {
     const int32_t *idx[2] = {b->stm, b->nstm};
     if (!side_behind) BT_HIP(hipStreamWaitEvent(n->side, n->ev_fork, 0));
     if (n->next_ready) BT_HIP(hipStreamWaitEvent(n->side, n->next_ready, 0));
-    if (int rc = bt_internal_ft_build_groups(n->side, &f, idx, n->ft_ws_alt, n->ft_ws_bytes)) return rc;
+    // The next step's FT forward needs the segment entry lists only; the bucket order and the sorted index are joined
+    // later (before the layers): ev_next_groups rides on the lists' last kernel (or is a packet of its own on the side
+    // stream when the table is not grouped and there is nothing to build)
+    const bool grouped = bt_internal_ft_grouped(&f);
+    if (int rc = bt_internal_ft_build_groups(n->side, &f, idx, n->ft_ws_alt, n->ft_ws_bytes, grouped ? n->ev_next_groups : nullptr))
+        return rc;
+    if (!grouped) BT_HIP(hipEventRecord(n->ev_next_groups, n->side));
     if (n->perm_alt && PermScope::perm_usable(n, b))
         if (int rc = bt_internal_bucket_perm(n->side, b->buckets, b->batch, n->d.num_buckets, n->perm_alt)) return rc;
     if (int rc = bt_internal_ft_build_sorted(n->side, &f, idx, n->ft_ws_alt, n->ft_ws_bytes)) return rc;
@@ -456,7 +463,8 @@ int bt_net_create(const bt_net_desc *desc, int max_batch, float *ext_params, flo
         hipEventCreateWithFlags(&n->ev_dfork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&n->ev_sums, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&n->ev_step, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&n->ev_next, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&n->ev_next, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&n->ev_next_groups, hipEventDisableTiming) != hipSuccess) {
         bt_set_error("bt_net_create: could not create the side stream / events");
         return fail(BT_ERR_HIP);
     }
@@ -478,6 +486,7 @@ int bt_net_destroy(bt_net *n) {
     if (n->ev_fwd) (void)hipEventDestroy(n->ev_fwd);
     if (n->ev_head) (void)hipEventDestroy(n->ev_head);
     if (n->ev_next) (void)hipEventDestroy(n->ev_next);
+    if (n->ev_next_groups) (void)hipEventDestroy(n->ev_next_groups);
     if (n->ev_dfork) (void)hipEventDestroy(n->ev_dfork);
     if (n->ev_sums) (void)hipEventDestroy(n->ev_sums);
     if (n->ev_step) (void)hipEventDestroy(n->ev_step);
@@ -558,7 +567,10 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
     n->prepared = false;
     if (ready) {
         std::swap(n->ft_ws, n->ft_ws_alt), std::swap(n->perm, n->perm_alt);
-        BT_HIP(hipStreamWaitEvent(s, n->ev_next, 0));  // (ev_fork for prepare_next: below, unless the tail forks anyway)
+        // (the entry lists now; the bucket order and the sorted index before the layers, forward_impl's join_layers: the
+        // side stream may still be building them when this step starts. ev_fork for prepare_next: below, unless the
+        // tail forks anyway)
+        BT_HIP(hipStreamWaitEvent(s, n->ev_next_groups, 0));
     } else {
         // segment-grouped tables: the entry lists are needed by the forward pass too, so they are built on `s` first
         // fork: sorted index build on the side stream, ordered after everything already queued on `s` (grouped tables:
@@ -607,7 +619,7 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
     // (the head's gradients come out of the FT backward and its merge: nothing runs beside them, nobody needs ev_fwd)
     const bool head_grads_in_ft = side_head && head_in_ft && bt_internal_ft_fused_head_grad_ok(&f, q0.buckets);
     if (int rc = forward_impl(n, s, b, fuse_loss && !tail, side_head, head_in_ft && !ready, true, perm.built && !ready,
-                              tail ? 1 : -1, !head_grads_in_ft))
+                              tail ? 1 : -1, !head_grads_in_ft, ready ? n->ev_next : nullptr))
         return rc;
     // The fused tail's gradient sums and layer 0's weight gradient are needed by the optimiser only: with the tail they
     // run on the side stream (behind the index build, if one is in flight there), beside dX and the FT backward,
