@@ -50,11 +50,10 @@ struct bt_net {
     void *ft_ws_alt = nullptr, *perm_alt = nullptr;
     bt_batch next = {}, prep_key = {};
     bool has_next = false, prepared = false;
-    // single-layer fused path: the side stream was ordered behind the previous step (its last kernel's completion
-    // event) and the hinted batch's ready event when that step ended, so this step needs no fork packet on `s`
-    bool primed = false;
-    bt_batch primed_key = {};
-    hipEvent_t ev_step = nullptr;
+    // single-layer fused path: the completion event that rode on the previous step's last kernel (ev_step, or the
+    // caller's done event). The side stream waits for it before it builds the next batch's index during this step, so
+    // this step needs no fork packet on `s`. Null after anything else was queued that reads the index workspace.
+    hipEvent_t ev_step = nullptr, prev_done = nullptr;
     hipEvent_t next_ready = nullptr, ev_next = nullptr, ev_next_groups = nullptr;
 };
 
@@ -260,7 +259,7 @@ int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bo
         // forward and the finishing kernel (it has long been satisfied), and "forward done" (ev_fwd) rides on the
         // finishing kernel's own dispatch packet instead of a separate hipEventRecord -- when somebody waits for it:
         // a completion signal on a packet delays the next kernel of the stream by 4-5 us too.
-        BT_HIP(hipStreamWaitEvent(s, n->ev_index, 0));
+        BT_HIP(hipStreamWaitEvent(s, join_layers ? join_layers : n->ev_index, 0));
         if (fwd_event) bt_attach_stop_event(BTK_DENSE_FWD_SMALL, n->ev_fwd);
         const int rc = bt_internal_head_finish(s, &q, n->zpart, bt_internal_ft_head_parts(&f), n->params + n->t_off[3], bk,
                                                b->targets, n->d.use_entry_weights ? b->entry_weights : nullptr, n->a[0],
@@ -323,12 +322,11 @@ int prepare_next(bt_net *n, bool side_behind) {
     if (!side_behind) BT_HIP(hipStreamWaitEvent(n->side, n->ev_fork, 0));
     if (n->next_ready) BT_HIP(hipStreamWaitEvent(n->side, n->next_ready, 0));
     // The next step's FT forward needs the segment entry lists only; the bucket order and the sorted index are joined
-    // later (before the layers): ev_next_groups rides on the lists' last kernel (or is a packet of its own on the side
-    // stream when the table is not grouped and there is nothing to build)
+    // later (before the layers): ev_next_groups rides on the lists' last kernel (a table that is not grouped has no lists
+    // and no such event)
     const bool grouped = bt_internal_ft_grouped(&f);
     if (int rc = bt_internal_ft_build_groups(n->side, &f, idx, n->ft_ws_alt, n->ft_ws_bytes, grouped ? n->ev_next_groups : nullptr))
         return rc;
-    if (!grouped) BT_HIP(hipEventRecord(n->ev_next_groups, n->side));
     if (n->perm_alt && PermScope::perm_usable(n, b))
         if (int rc = bt_internal_bucket_perm(n->side, b->buckets, b->batch, n->d.num_buckets, n->perm_alt)) return rc;
     if (int rc = bt_internal_ft_build_sorted(n->side, &f, idx, n->ft_ws_alt, n->ft_ws_bytes)) return rc;
@@ -515,6 +513,7 @@ int bt_net_set_adamw(bt_net *n, int t, float decay, float beta1, float beta2, fl
 int bt_net_forward(bt_net *n, void *stream, const bt_batch *b, float *out_dev, float *loss_sum_dev) {
     if (int rc = check_batch(n, b, "bt_net_forward")) return rc;
     hipStream_t s = bt_stream(stream);
+    n->prev_done = nullptr;  // (this pass uses the index workspace after the last step's completion event)
     PermScope perm(n, s, b);
     if (perm.rc) return perm.rc;
     if (int rc = forward_impl(n, s, b, false)) return rc;
@@ -570,22 +569,19 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
         // (the entry lists now; the bucket order and the sorted index before the layers, forward_impl's join_layers: the
         // side stream may still be building them when this step starts. ev_fork for prepare_next: below, unless the
         // tail forks anyway)
-        BT_HIP(hipStreamWaitEvent(s, n->ev_next_groups, 0));
+        if (bt_internal_ft_grouped(&f)) BT_HIP(hipStreamWaitEvent(s, n->ev_next_groups, 0));
     } else {
         // segment-grouped tables: the entry lists are needed by the forward pass too, so they are built on `s` first
         // fork: sorted index build on the side stream, ordered after everything already queued on `s` (grouped tables:
         // the fork event rides on the entry lists' last kernel instead of a packet of its own)
-        const bool primed = n->primed && n->primed_key.batch == b->batch && n->primed_key.stm == b->stm &&
-                            n->primed_key.nstm == b->nstm && n->primed_key.buckets == b->buckets;
-        const bool ride = !primed && bt_internal_ft_grouped(&f);
+        const bool ride = bt_internal_ft_grouped(&f);
         if (int rc = bt_internal_ft_build_groups(s, &f, idx, n->ft_ws, n->ft_ws_bytes, ride ? n->ev_fork : nullptr))
             return rc;
-        if (!primed) {
-            if (!ride) BT_HIP(hipEventRecord(n->ev_fork, s));
-            BT_HIP(hipStreamWaitEvent(n->side, n->ev_fork, 0));
-        }
+        if (!ride) BT_HIP(hipEventRecord(n->ev_fork, s));
+        BT_HIP(hipStreamWaitEvent(n->side, n->ev_fork, 0));
     }
-    n->primed = false;
+    hipEvent_t prev_done = n->prev_done;
+    n->prev_done = nullptr;
     PermScope perm(n, n->side, b, !ready);  // (multi-layer bucketed nets) needed after the FT forward: side stream first
     if (perm.rc) return perm.rc;
     if (!ready) {
@@ -615,10 +611,15 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
     const bool tail_gz = tail && !bt_internal_dense_head_ok(&q0) && bt_internal_dense_takes_gz(&q0);
     // Every packet on `s` costs a bubble of ~5 us: with the fused tail the side stream is put behind the tail kernel of
     // this step (SideSums below), which orders prepare_next behind the previous step as well.
-    if (ready && !tail) BT_HIP(hipEventRecord(n->ev_fork, s));
     // (the head's gradients come out of the FT backward and its merge: nothing runs beside them, nobody needs ev_fwd)
     const bool head_grads_in_ft = side_head && head_in_ft && bt_internal_ft_fused_head_grad_ok(&f, q0.buckets);
-    if (int rc = forward_impl(n, s, b, fuse_loss && !tail, side_head, head_in_ft && !ready, true, perm.built && !ready,
+    // The side stream's work for the NEXT batch (prepare_next) has to stay behind the last readers of the second buffer
+    // set, the step before this one. Single-layer fused path: behind that step's completion event, which rode on its
+    // merge kernel -- no packet on `s` at all. Otherwise behind a fork event recorded on `s` here.
+    const bool fork_by_done = ready && head_grads_in_ft && prev_done;
+    if (fork_by_done) BT_HIP(hipStreamWaitEvent(n->side, prev_done, 0));
+    else if (ready && !tail) BT_HIP(hipEventRecord(n->ev_fork, s));
+    if (int rc = forward_impl(n, s, b, fuse_loss && !tail, side_head, head_in_ft, true, perm.built && !ready,
                               tail ? 1 : -1, !head_grads_in_ft, ready ? n->ev_next : nullptr))
         return rc;
     // The fused tail's gradient sums and layer 0's weight gradient are needed by the optimiser only: with the tail they
@@ -661,7 +662,6 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
         // beside its LDS-bound reduction), and its merge kernel adds up the head's bias gradient and the loss from
         // the finishing kernel's partials: no second stream, no second pass over the [B][2H] activations.
         const bool hinted = n->has_next;
-        n->has_next = false;
         bt_ft_head_grads hg{n->grads + n->t_off[2], n->grads + n->t_off[3], n->gz_parts, n->loss_partials,
                             n->n_loss_partials, loss_sum_dev};
         bt_ft_fused_adamw fa;
@@ -670,21 +670,18 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
             fa.adj = opt->adj, fa.lr = opt->lr;
             hg.step = &fa, hg.done = opt->done, opt->stepped = true;
         }
-        // A hinted next batch: its index build (side stream, next step) has to wait for this step's last reader of the
-        // index workspace and for the batch itself. Both waits are queued on the side stream now -- the first on the
-        // completion event that rides on the merge kernel's packet -- and the next step forks without a packet on `s`.
+        // A hinted next batch: its index is built on the side stream during this step, into the second buffer set
+        // (prepare_next). The batch after it will be built during the next step, behind this step's completion event,
+        // which rides on the merge kernel's packet.
         if (hinted && !hg.done) hg.done = n->ev_step;
         if (int rc = bt_internal_ft_backward_fused(s, &f, n->gz0, n->params + n->t_off[2],
                                                    n->d.dense_bucketed[0] ? b->buckets : nullptr, q0.buckets, n->hid,
                                                    n->saved, n->grads + n->t_off[0], n->grads + n->t_off[1], n->ft_ws,
                                                    n->ft_ws_bytes, &hg))
             return rc;
-        if (hinted) {
-            BT_HIP(hipStreamWaitEvent(n->side, hg.done, 0));
-            if (n->next_ready) BT_HIP(hipStreamWaitEvent(n->side, n->next_ready, 0));
-            n->primed = true, n->primed_key = n->next;
-        }
-        return factor_reduce();
+        if (int rc = factor_reduce()) return rc;
+        if (hinted && n->d.ft_factoriser <= 0) n->prev_done = hg.done;  // (the merge is this step's last kernel)
+        return prepare_next(n, fork_by_done);
     }
     if (side_head) {
         // (a next-batch hint is not used here: this path's index build already hides under the forward pass, and
@@ -698,7 +695,7 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
                                                      n->dense_ws, n->dense_ws_bytes, true))
             return rc;
         BT_HIP(hipEventRecord(n->ev_head, n->side));
-        if (!head_in_ft) BT_HIP(hipStreamWaitEvent(s, n->ev_index, 0));  // (head_in_ft: joined inside forward_impl)
+        if (!head_in_ft && !ready) BT_HIP(hipStreamWaitEvent(s, n->ev_index, 0));  // (else: joined inside forward_impl)
         if (int rc = bt_internal_ft_backward_fused(s, &f, n->gz0, n->params + n->t_off[2],
                                                    n->d.dense_bucketed[0] ? b->buckets : nullptr, q0.buckets, n->hid,
                                                    n->saved, n->grads + n->t_off[0], n->grads + n->t_off[1], n->ft_ws,
