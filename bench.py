@@ -270,6 +270,7 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
         upload(0, 0, stream)
     lib.check(L.bt_event_record(uploaded[0], stream))
     counter = [0]
+    waited = [0.0]
     landed = C.c_int(0)
 
     def step():
@@ -284,6 +285,10 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
             if i >= 2:
                 if "devwait" in X:
                     L.bt_stream_wait_event(copy, consumed[nxt])
+                elif "hosttime" in X:  # (developer aid: how long the host waits for the GPU, i.e. its slack per step)
+                    t_w = time.perf_counter()
+                    L.bt_event_sync(consumed[nxt])
+                    waited[0] += time.perf_counter() - t_w
                 else:
                     L.bt_event_sync(consumed[nxt])
             upload((i + 1) % n_distinct, nxt, copy)
@@ -346,10 +351,15 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
     if profile and dom:
         lib.profile_start(steps * 2 + 64, only=[dom], every=SAMPLE)
     torch.cuda.synchronize()
+    waited[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
+    if "hosttime" in X:
+        print(f"host: {(t_host - waited[0]) / steps * 1e6:.1f} us busy, {waited[0] / steps * 1e6:.1f} us waiting per step",
+              file=sys.stderr)
     if comm is not None:
         comm.barrier(stream)
     elapsed = time.perf_counter() - t0

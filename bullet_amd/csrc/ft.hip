@@ -268,7 +268,7 @@ __global__ __launch_bounds__(GRP_BLOCK) void ft_group_place(const uint8_t *__res
     }
 }
 
-// ------------------------------------------------------------------ index build (shared by all backward paths)
+// ------------------------------------------------------------------ index build of the any-shape backward
 // One workgroup per chunk.  W waves; wave w owns the contiguous entry sub-range w of the chunk and a
 // private per-feature counter row, so the fill pass is race-free and stable without cross-wave ordering.
 //   pass 0: n_valid per entry (first invalid index ends the list)
@@ -276,12 +276,10 @@ __global__ __launch_bounds__(GRP_BLOCK) void ft_group_place(const uint8_t *__res
 //   scan  : exclusive scan in (feature major, wave minor) order -> start[w][f]; offs[chunk][f] to global
 //   pass 2: each wave walks its entries in order, 64/nnz_pad entries per step; lanes with equal feature
 //           rank themselves by ballot (one ballot per feature-id bit) and take consecutive slots.
-// GRP: chunk c is a slice of the segment-grouped entry list; `cols` is the segment width, features are stored
-// relative to the segment, `cols_total` bounds the stop rule.
-template <bool GRP>
+// (tables that fit the LDS kernels, segment-grouped or not, use ft_index_oct_kernel instead)
 __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t *__restrict__ idx1, int batch,
                                 int nnz, int cols, int chunks_per_input, int fbits, uint16_t *__restrict__ sorted,
-                                uint32_t *__restrict__ offs, FtGrp gp, int cols_total) {
+                                uint32_t *__restrict__ offs) {
     extern __shared__ uint32_t lds[];
     const int nwaves = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6;
@@ -290,19 +288,11 @@ __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t 
     uint32_t *tsum = lds + (size_t)nwaves * cols;  // [blockDim.x] scan scratch
 
     const int c = blockIdx.x;
-    int n_e, col0 = 0, start0 = 0;
-    const int32_t *idx = nullptr;
-    if constexpr (GRP) {
-        if (c >= gp.counts[2]) return;
-        const int4 ch = gp.chunks[c];
-        col0 = ch.x * cols, start0 = ch.y, n_e = ch.z;
-    } else {
-        const int k = c / chunks_per_input;
-        const int cb = c % chunks_per_input;
-        const int b0 = cb * FT_CHUNK;
-        n_e = min(FT_CHUNK, batch - b0);
-        idx = (k == 0 ? idx0 : idx1) + (size_t)b0 * nnz;
-    }
+    const int k = c / chunks_per_input;
+    const int cb = c % chunks_per_input;
+    const int b0 = cb * FT_CHUNK;
+    const int n_e = min(FT_CHUNK, batch - b0);
+    const int32_t *idx = (k == 0 ? idx0 : idx1) + (size_t)b0 * nnz;
     uint16_t *my_sorted = sorted + (size_t)c * ft_sorted_cap(nnz, cols);
     uint32_t *my_offs = offs + (size_t)c * (cols + 1);
 
@@ -324,15 +314,7 @@ __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t 
     constexpr int IDX_REG = 16;
     const int nsteps = (per_wave + eps - 1) / eps;
     // index slot `li` of chunk-local entry e (callers guarantee e < e_hi, li < nnz)
-    auto load_j = [&](int e) -> int {
-        if constexpr (GRP) {
-            const int eid = gp.elist[start0 + e];
-            const int k2 = eid >= batch ? 1 : 0;
-            return (k2 ? idx1 : idx0)[(size_t)(eid - k2 * batch) * nnz + li];
-        } else {
-            return idx[(size_t)e * nnz + li];
-        }
-    };
+    auto load_j = [&](int e) -> int { return idx[(size_t)e * nnz + li]; };
     int jr[IDX_REG];
 #pragma unroll
     for (int st = 0; st < IDX_REG; st++) {
@@ -342,20 +324,15 @@ __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t 
     const unsigned long long seg = (slot == 64) ? ~0ull : (((1ull << slot) - 1) << (sub * slot));
     // list length of this lane's entry: the first invalid index ends it (write.rs:231)
     auto n_valid = [&](int e, int j) {
-        const bool inval = (e < e_hi) && (li >= nnz || j < 0 || j >= cols_total);
+        const bool inval = (e < e_hi) && (li >= nnz || j < 0 || j >= cols);
         const unsigned long long m = __ballot(inval) & seg;
         return m ? (__ffsll((long long)m) - 1 - sub * slot) : slot;
     };
 
     // pass 1
-    // GRP: a listed index outside the entry's segment breaks the caller's promise: flagged, not counted
-    auto in_seg = [&](int jl) { return !GRP || (jl >= 0 && jl < cols); };
     auto count_step = [&](int e, int j) {
         const int nvalid = n_valid(e, j);
-        if (e < e_hi && li < nvalid) {
-            if (in_seg(j - col0)) atomicAdd(&cnt[(size_t)wave * cols + (j - col0)], 1u);
-            else if constexpr (GRP) atomicAdd(gp.viol, 1);
-        }
+        if (e < e_hi && li < nvalid) atomicAdd(&cnt[(size_t)wave * cols + j], 1u);
     };
 #pragma unroll
     for (int st = 0; st < IDX_REG; st++)
@@ -402,10 +379,9 @@ __global__ void ft_index_kernel(const int32_t *__restrict__ idx0, const int32_t 
     // pass 2
     uint32_t *start = cnt + (size_t)wave * cols;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    auto place_step = [&](int e, int jraw) {
-        const int nvalid = n_valid(e, jraw);
-        const int j = jraw - col0;
-        const bool active = (e < e_hi) && (li < nvalid) && in_seg(j);
+    auto place_step = [&](int e, int j) {
+        const int nvalid = n_valid(e, j);
+        const bool active = (e < e_hi) && (li < nvalid);
         // lanes holding the same feature
         unsigned long long peers = __ballot(active);
         for (int bit = 0; bit < fbits; bit++) {
@@ -2364,12 +2340,9 @@ int bt_internal_ft_build_sorted(void *stream, const bt_ft_desc *d, const int32_t
         BT_LAUNCH_CHECK();
         return BT_OK;
     }
-    if (p.grouped)
-        BT_LAUNCH(BTK_FT_INDEX, s, ft_index_kernel<true>, dim3(p.nchunks), dim3(threads), lds, i0, i1, d->batch, d->nnz,
-                  p.tc, 1, p.fbits, sorted, offs, gp, d->cols);
-    else
-        BT_LAUNCH(BTK_FT_INDEX, s, ft_index_kernel<false>, dim3(p.nchunks), dim3(threads), lds, i0, i1, d->batch, d->nnz,
-                  d->cols, p.chunks_per_input, p.fbits, sorted, offs, gp, d->cols);
+    // (a segment-grouped table fits the LDS kernels by definition, ft_plan: it took the branch above)
+    BT_LAUNCH(BTK_FT_INDEX, s, ft_index_kernel, dim3(p.nchunks), dim3(threads), lds, i0, i1, d->batch, d->nnz, d->cols,
+              p.chunks_per_input, p.fbits, sorted, offs);
     BT_LAUNCH_CHECK();
     return BT_OK;
 }
