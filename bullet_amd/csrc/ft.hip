@@ -31,9 +31,10 @@ __host__ __device__ inline int ft_sorted_cap(int nnz, int cols) { return (FT_CHU
 
 // Test switches, read from the environment when the library is loaded and again only when a test asks for it
 // (bt_internal_reload_env): BT_FT_FORCE_GENERIC=1 runs the any-shape kernels on every shape, BT_FT_FORCE_GROUPED=1
-// the segment-grouped ones wherever a segment is given, BT_FT_FWD_ITEM / BT_FT_BWD_CHUNKS override the item sizes.
+// the segment-grouped ones wherever a segment is given, BT_FT_FWD_ITEM / BT_FT_BWD_CHUNKS override the item sizes,
+// BT_FT_NO_PREDEC=1 makes the fused-head forward decode its lists itself (as the op-level forward does).
 struct FtEnv {
-    bool force_generic = false, force_grouped = false;
+    bool force_generic = false, force_grouped = false, no_predec = false;
     int fwd_item = 0, bwd_chunks = 0;
     FtEnv() { reload(); }
     void reload() {
@@ -43,6 +44,7 @@ struct FtEnv {
         };
         force_generic = num("BT_FT_FORCE_GENERIC") == 1, force_grouped = num("BT_FT_FORCE_GROUPED") != 0;
         fwd_item = num("BT_FT_FWD_ITEM"), bwd_chunks = num("BT_FT_BWD_CHUNKS");
+        no_predec = num("BT_FT_NO_PREDEC") == 1;
     }
 };
 FtEnv g_ft_env;
@@ -922,12 +924,55 @@ __device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lanes of
 // GRP (bt_ft_desc.segment): the workgroup is (row tile, forward item); the tile holds the item's segment of
 // `tc` columns, entries come from the grouped list, and one more LDS row (all NaN) receives the slots whose
 // index lies outside the segment, so a broken promise poisons the entry's output instead of passing silently.
-template <bool PAIR, bool ALIGNED4, int NROUND, bool HEAD, bool GRP>
+// The forward's list decode, once per batch instead of once per row tile: 8 threads per entry, 4 slots each, as the
+// decode map of ft_fwd_lds. offs[e][32]: byte offset of the tile row of every slot, masked slots (behind the first
+// invalid index, write.rs:231) -> the zero row `cols`; nblk[e / 8]: the 4-slot blocks that hold a live slot for at
+// least one of the group's eight entries (live blocks form a prefix in every entry).
+__global__ __launch_bounds__(256) void ft_fwd_decode_kernel(const int32_t *__restrict__ idx0,
+                                                            const int32_t *__restrict__ idx1, int batch, int nnz, int cols,
+                                                            int E, lds_u4_t *__restrict__ offs, uint8_t *__restrict__ nblk) {
+    const int t = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    const int e = t >> 3, sub = t & 7, eslot = lane >> 3;
+    const int ec = min(e, E - 1), k = ec >= batch ? 1 : 0;
+    const int32_t *ip = (k ? idx1 : idx0) + (size_t)(ec - k * batch) * nnz;
+    bool inv[4];
+    int r[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int p = sub * 4 + j;
+        r[j] = ip[min(p, nnz - 1)];
+        inv[j] = p >= nnz || r[j] < 0 || r[j] >= cols;
+    }
+    const bool any = inv[0] | inv[1] | inv[2] | inv[3];
+    const unsigned m = (unsigned)(__ballot(any) >> (eslot * 8)) & 0xFFu;
+    bool kill = e >= E || (m & ((1u << sub) - 1u));
+    const unsigned long long open = __ballot(!(kill || inv[0]));
+    lds_u4_t o;
+    kill |= inv[0], o.x = (unsigned)(kill ? cols : r[0]) * (LDS_RT * 4);
+    kill |= inv[1], o.y = (unsigned)(kill ? cols : r[1]) * (LDS_RT * 4);
+    kill |= inv[2], o.z = (unsigned)(kill ? cols : r[2]) * (LDS_RT * 4);
+    kill |= inv[3], o.w = (unsigned)(kill ? cols : r[3]) * (LDS_RT * 4);
+    if (e < E) offs[(size_t)e * 8 + sub] = o;
+    unsigned fold = (unsigned)open | (unsigned)(open >> 32);
+    fold |= fold >> 16;
+    fold |= fold >> 8;
+    if (lane == 0 && e < E) nblk[e >> 3] = (uint8_t)__popc(fold & 0xFFu);
+}
+
+// PRE: the lists were validated and decoded once per batch (ft_fwd_decode_kernel) instead of once per row tile here:
+// pre.offs holds each entry's 32 strip words as the decode below would form them, pre.nblk the live 4-slot blocks of
+// every aligned group of 8 entries. Same rows in the same order, so the same bits.
+struct FtPre {
+    const lds_u4_t *offs;  // [E][8]
+    const uint8_t *nblk;   // [ceil(E / 8)]
+};
+template <bool PAIR, bool ALIGNED4, int NROUND, bool HEAD, bool GRP, bool PRE = false>
 __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restrict__ w, const float *__restrict__ bias,
                                                           const int32_t *__restrict__ idx0,
                                                           const int32_t *__restrict__ idx1, float *__restrict__ out,
                                                           float *__restrict__ saved, bt_ft_desc d, int ntiles,
-                                                          int entries_per_wg, FtHeadSink hs, FtGrp gp) {
+                                                          int entries_per_wg, FtHeadSink hs, FtGrp gp, FtPre pre) {
+    static_assert(!PRE || (NROUND == 1 && !GRP), "pre-decoded lists: one round, not segment-grouped");
     extern __shared__ __align__(16) float wl[];  // [(tc + 1)][32]; row `tc` is all zero (target of masked slots)
     constexpr int SS = fwd_strip_words(NROUND);
     constexpr int TW = PAIR ? 16 : 32;  // output columns per perspective covered by this row tile
@@ -1010,6 +1055,13 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
     };
     int nxt[NROUND][4];
     const int eb0 = e_begin + wave * FWD_EPW;
+    // PRE: this lane's four strip words of entry `pos` and the block count of the pass that starts at entry `pos0`
+    auto load_pre = [&](int pos, int(&r)[NROUND][4]) {
+        const lds_u4_t v = pre.offs[(size_t)min(pos, E - 1) * 8 + sub];
+        r[0][0] = (int)v.x, r[0][1] = (int)v.y, r[0][2] = (int)v.z, r[0][3] = (int)v.w;
+    };
+    auto load_nblk = [&](int pos0) -> int { return PRE ? (int)pre.nblk[min(pos0, E - 1) >> 3] : 0; };
+    int nxt_nblk = load_nblk(eb0);
     // GRP: entry ids are fetched two passes ahead (decode map d1/d2, gather map g0/g1), so the index and bucket
     // loads that depend on them are still issued one full pass before use
     int d1 = 0, d2 = 0, g0 = 0, g1 = 0;
@@ -1017,7 +1069,8 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
         d1 = ent(eb0 + PASS + eslot), d2 = ent(eb0 + 2 * PASS + eslot);
         g0 = ent(eb0 + ge), g1 = ent(eb0 + PASS + ge);
     }
-    load_idx(ent(eb0 + eslot), nxt);
+    if constexpr (PRE) load_pre(eb0 + eslot, nxt);
+    else load_idx(ent(eb0 + eslot), nxt);
     int nxt_bk = load_bucket(GRP ? g0 : ent(eb0 + ge));
     for (int eb = eb0; eb < e_end; eb += PASS) {
         // rotate the issue priority among the four waves of a SIMD every four passes: they would otherwise issue
@@ -1044,14 +1097,23 @@ __global__ __launch_bounds__(LDS_THREADS) void ft_fwd_lds(const float *__restric
         if constexpr (GRP) {
             load_idx(d1, nxt);
             d1 = d2, d2 = ent(eb + 3 * PASS + eslot);
+        } else if constexpr (PRE) {
+            load_pre(eb + PASS + eslot, nxt);
         } else {
             load_idx(ent(eb + PASS + eslot), nxt);
         }
         // decode: slot p is masked iff any slot <= p of the same entry is invalid
         bool dead = eb + eslot >= e_end;
         int nblk = 0;  // wave-uniform: 4-slot blocks that hold a live slot for at least one entry
+        if constexpr (PRE) {
+            lds_u4_t o;
+            o.x = (unsigned)reg[0][0], o.y = (unsigned)reg[0][1], o.z = (unsigned)reg[0][2], o.w = (unsigned)reg[0][3];
+            *reinterpret_cast<lds_u4_t *>(dstrip + sub * 4) = o;
+            nblk = __builtin_amdgcn_readfirstlane(nxt_nblk);
+            nxt_nblk = load_nblk(eb + PASS);
+        }
 #pragma unroll
-        for (int q = 0; q < NROUND; q++) {
+        for (int q = 0; q < (PRE ? 0 : NROUND); q++) {
             bool inv[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -1902,6 +1964,9 @@ struct FtPlan {
     // head weight gradient formed inside the fused backward (ft_bwd_oct<HDW>): per-chunk-group partials of dW1
     bool hdw;
     size_t off_pw1, pw1_stride;
+    // forward lists decoded once per batch (ft_fwd_decode_kernel, read by ft_fwd_lds<PRE>)
+    bool predec;
+    size_t off_foffs, off_fblk;
 };
 
 int ft_validate(const bt_ft_desc *d, const char *who) {
@@ -2021,6 +2086,12 @@ int ft_plan(const bt_ft_desc *d, FtPlan *p) {
     p->hdw = p->oct && !p->grouped && !d->pairwise && p->chunks_per_input % p->chunks_per_wg == 0 &&
              (size_t)p->tc * LDS_RT >= (size_t)(LDS_THREADS / 64) * FtPlan::kFusedMaxRows * 64;
     if (p->hdw) p->off_pw1 = o, o += bt_align((size_t)p->G * p->pw1_stride * sizeof(float));
+    p->predec = p->lds_path && !p->grouped && d->nnz <= 32 && !g_ft_env.no_predec;
+    p->off_foffs = p->off_fblk = 0;
+    if (p->predec) {
+        p->off_foffs = o, o += bt_align((size_t)E * 32 * sizeof(uint32_t));
+        p->off_fblk = o, o += bt_align((size_t)bt_div_up(E, 8));
+    }
     p->total = o;
     return BT_OK;
 }
@@ -2185,7 +2256,8 @@ size_t ft_head_lds_bytes(const bt_ft_desc *d, int head_rows) {
 
 int ft_forward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, const float *w, const float *bias,
                           const int32_t *i0, const int32_t *i1, float *out, float *saved, const FtHeadSink *head,
-                          char *ws = nullptr) {
+                          char *ws = nullptr, bool pre_decoded = false) {
+    pre_decoded = pre_decoded && p.predec && head && ws;
     const long long E = (long long)d->n_inputs * d->batch;
     int G = 256 / p.ntiles;
     if (G < 1) G = 1;
@@ -2207,7 +2279,7 @@ int ft_forward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, c
     do {                                                                                                            \
         if (int rc = set_lds(ft_fwd_lds<PAIR, true, 1, HEAD, true>, lds)) return rc;                                \
         BT_LAUNCH(BTK_FT_FWD_LDS, s, (ft_fwd_lds<PAIR, true, 1, HEAD, true>), ggrid, lblock, lds, w, bias, i0, i1, out, \
-                  saved, *d, p.ntiles, 0, hs, gp);                                                                  \
+                  saved, *d, p.ntiles, 0, hs, gp, FtPre{});                                                         \
     } while (0)
         if (d->pairwise) {
             if (head) FWD_GRP(true, true);
@@ -2220,11 +2292,25 @@ int ft_forward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, c
         BT_LAUNCH_CHECK();
         return BT_OK;
     }
+    if (pre_decoded) {  // (the caller ran bt_internal_ft_build_groups on this batch: net.hip's head path)
+        const FtPre pre{reinterpret_cast<const lds_u4_t *>(ws + p.off_foffs), reinterpret_cast<const uint8_t *>(ws + p.off_fblk)};
+#define FWD_PRE(PAIR)                                                                                              \
+    do {                                                                                                           \
+        if (int rc = set_lds(ft_fwd_lds<PAIR, true, 1, true, false, true>, lds)) return rc;                        \
+        BT_LAUNCH(BTK_FT_FWD_LDS, s, (ft_fwd_lds<PAIR, true, 1, true, false, true>), lgrid, lblock, lds, w, bias, i0, i1, \
+                  out, saved, *d, p.ntiles, (int)epw, hs, FtGrp{}, pre);                                           \
+    } while (0)
+        if (d->pairwise) FWD_PRE(true);
+        else FWD_PRE(false);
+#undef FWD_PRE
+        BT_LAUNCH_CHECK();
+        return BT_OK;
+    }
 #define FWD_LDS(PAIR, AL4, NROUND, HEAD)                                                                           \
     do {                                                                                                           \
         if (int rc = set_lds(ft_fwd_lds<PAIR, AL4, NROUND, HEAD, false>, lds)) return rc;                          \
         BT_LAUNCH(BTK_FT_FWD_LDS, s, (ft_fwd_lds<PAIR, AL4, NROUND, HEAD, false>), lgrid, lblock, lds, w, bias, i0, i1, \
-                  out, saved, *d, p.ntiles, (int)epw, hs, FtGrp{});                                                \
+                  out, saved, *d, p.ntiles, (int)epw, hs, FtGrp{}, FtPre{});                                       \
     } while (0)
 #define FWD_LDS3(PAIR, AL4, NROUND)                                                                                \
     do {                                                                                                           \
@@ -2275,8 +2361,9 @@ int bt_internal_ft_forward_head(void *stream, const bt_ft_desc *d, const float *
     if (int rc = ft_plan(d, &p)) return rc;
     BT_REQUIRE(!p.grouped || (workspace && workspace_bytes >= p.total), "bt_ft_forward(head): workspace too small");
     const FtHeadSink hs{w1, bucket, head_rows, zpart};
+    BT_REQUIRE(!p.predec || !workspace || workspace_bytes >= p.total, "bt_ft_forward(head): workspace too small");
     return ft_forward_lds_launch(bt_stream(stream), d, p, w, bias, idx[0], d->n_inputs > 1 ? idx[1] : idx[0], out, saved,
-                                 &hs, static_cast<char *>(workspace));
+                                 &hs, static_cast<char *>(workspace), workspace != nullptr);
 }
 
 // ---- internal: the two halves of bt_ft_build_index. The entry lists (segment-grouped tables only) are needed by
@@ -2289,11 +2376,19 @@ int bt_internal_ft_build_groups(void *stream, const bt_ft_desc *d, const int32_t
     FtPlan p;
     if (int rc = ft_plan(d, &p)) return rc;
     BT_REQUIRE(workspace_bytes >= p.total, "bt_ft_build_index: workspace too small (%zu < %zu)", workspace_bytes, p.total);
-    if (!p.grouped) return BT_OK;
     hipStream_t s = bt_stream(stream);
     char *ws = static_cast<char *>(workspace);
     const int32_t *i0 = idx[0], *i1 = d->n_inputs > 1 ? idx[1] : idx[0];
     const int E = d->n_inputs * d->batch;
+    if (p.predec) {
+        if (done) bt_attach_stop_event(BTK_FT_INDEX, done);
+        BT_LAUNCH(BTK_FT_INDEX, s, ft_fwd_decode_kernel, dim3(bt_div_up((long long)E * 8, 256)), dim3(256), 0, i0, i1, d->batch,
+                  d->nnz, d->cols, E, reinterpret_cast<lds_u4_t *>(ws + p.off_foffs),
+                  reinterpret_cast<uint8_t *>(ws + p.off_fblk));
+        BT_LAUNCH_CHECK();
+        return BT_OK;
+    }
+    if (!p.grouped) return BT_OK;
     uint8_t *seg_of = reinterpret_cast<uint8_t *>(ws + p.off_segof);
     int *blk = reinterpret_cast<int *>(ws + p.off_blkcnt);
     BT_LAUNCH(BTK_FT_INDEX, s, ft_group_count, dim3(p.grp_blocks), dim3(GRP_BLOCK), 0, i0, i1, d->batch, d->nnz, d->cols,

@@ -239,7 +239,7 @@ struct PermScope {
 // fwd_event: record ev_fwd when the forward pass is complete (the side-stream head backward waits for it)
 int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bool want_gz0 = false,
                  bool head_in_ft = false, bool groups_ready = false, bool perm_on_side = false, int n_layers = -1,
-                 bool fwd_event = true, hipEvent_t join_layers = nullptr) {
+                 bool fwd_event = true, hipEvent_t join_layers = nullptr, bool joined = false) {
     bt_ft_desc f = ft_desc(n, b->batch);
     const int32_t *idx[2] = {b->stm, b->nstm};
     const float *w0 = nullptr;
@@ -259,7 +259,7 @@ int forward_impl(bt_net *n, hipStream_t s, const bt_batch *b, bool fuse_loss, bo
         // forward and the finishing kernel (it has long been satisfied), and "forward done" (ev_fwd) rides on the
         // finishing kernel's own dispatch packet instead of a separate hipEventRecord -- when somebody waits for it:
         // a completion signal on a packet delays the next kernel of the stream by 4-5 us too.
-        BT_HIP(hipStreamWaitEvent(s, join_layers ? join_layers : n->ev_index, 0));
+        if (!joined) BT_HIP(hipStreamWaitEvent(s, join_layers ? join_layers : n->ev_index, 0));
         if (fwd_event) bt_attach_stop_event(BTK_DENSE_FWD_SMALL, n->ev_fwd);
         const int rc = bt_internal_head_finish(s, &q, n->zpart, bt_internal_ft_head_parts(&f), n->params + n->t_off[3], bk,
                                                b->targets, n->d.use_entry_weights ? b->entry_weights : nullptr, n->a[0],
@@ -564,12 +564,19 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
     const bool ready = n->prepared && n->prep_key.batch == b->batch && n->prep_key.stm == b->stm &&
                        n->prep_key.nstm == b->nstm && n->prep_key.buckets == b->buckets;
     n->prepared = false;
+    bool joined = false;  // ready: the side stream's build of this batch has been joined in full already
     if (ready) {
         std::swap(n->ft_ws, n->ft_ws_alt), std::swap(n->perm, n->perm_alt);
         // (the entry lists now; the bucket order and the sorted index before the layers, forward_impl's join_layers: the
         // side stream may still be building them when this step starts. ev_fork for prepare_next: below, unless the
         // tail forks anyway)
+        // A table that is not grouped: one join, here (its forward may read lists decoded on the side stream, and the
+        // whole build ended during the previous step anyway).
         if (bt_internal_ft_grouped(&f)) BT_HIP(hipStreamWaitEvent(s, n->ev_next_groups, 0));
+        else {
+            BT_HIP(hipStreamWaitEvent(s, n->ev_next, 0));
+            joined = true;
+        }
     } else {
         // segment-grouped tables: the entry lists are needed by the forward pass too, so they are built on `s` first
         // fork: sorted index build on the side stream, ordered after everything already queued on `s` (grouped tables:
@@ -620,7 +627,7 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
     if (fork_by_done) BT_HIP(hipStreamWaitEvent(n->side, prev_done, 0));
     else if (ready && !tail) BT_HIP(hipEventRecord(n->ev_fork, s));
     if (int rc = forward_impl(n, s, b, fuse_loss && !tail, side_head, head_in_ft, true, perm.built && !ready,
-                              tail ? 1 : -1, !head_grads_in_ft, ready ? n->ev_next : nullptr))
+                              tail ? 1 : -1, !head_grads_in_ft, ready && !joined ? n->ev_next : nullptr, joined))
         return rc;
     // The fused tail's gradient sums and layer 0's weight gradient are needed by the optimiser only: with the tail they
     // run on the side stream (behind the index build, if one is in flight there), beside dX and the FT backward,
