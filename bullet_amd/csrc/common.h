@@ -16,8 +16,8 @@ int bt_internal_sf_source(const char *const *paths, int n_paths, size_t buffer_s
                           void *user, uint64_t shuffle_seed, std::function<int(std::vector<uint8_t> &)> *out_refill);
 // viribinpack.cpp: a source of shuffled 32-byte records for bt_reader (each call delivers one full shuffle buffer)
 int bt_internal_viri_source(const char *const *paths, int n_paths, size_t buffer_size_mb, int threads,
-                            bt_viri_filter filter, void *user, uint64_t shuffle_seed,
-                            std::function<int(std::vector<uint8_t> &)> *out_refill);
+                            bt_viri_filter filter, void *user, const bt_viri_builtin_filter *builtin,
+                            uint64_t shuffle_seed, std::function<int(std::vector<uint8_t> &)> *out_refill);
 
 void bt_set_error(const char *fmt, ...);
 

@@ -330,7 +330,23 @@ extern "C" int bt_reader_open_viribinpack(const char *const *paths, int n_paths,
                                           bt_viri_filter filter, void *user, uint64_t shuffle_seed, bt_reader **out) {
     BT_REQUIRE(out, "bt_reader_open_viribinpack: bad arguments");
     bt_reader *r = new bt_reader();
-    if (int rc = bt_internal_viri_source(paths, n_paths, buffer_size_mb, threads, filter, user, shuffle_seed, &r->refill)) {
+    if (int rc = bt_internal_viri_source(paths, n_paths, buffer_size_mb, threads, filter, user, nullptr, shuffle_seed,
+                                         &r->refill)) {
+        delete r;
+        return rc;
+    }
+    r->clock_seeded = shuffle_seed == 0;
+    *out = r;
+    return BT_OK;
+}
+
+extern "C" int bt_reader_open_viribinpack_builtin(const char *const *paths, int n_paths, size_t buffer_size_mb, int threads,
+                                                  const bt_viri_builtin_filter *filter, uint64_t shuffle_seed,
+                                                  bt_reader **out) {
+    BT_REQUIRE(out && filter, "bt_reader_open_viribinpack_builtin: bad arguments");
+    bt_reader *r = new bt_reader();
+    if (int rc = bt_internal_viri_source(paths, n_paths, buffer_size_mb, threads, nullptr, nullptr, filter, shuffle_seed,
+                                         &r->refill)) {
         delete r;
         return rc;
     }

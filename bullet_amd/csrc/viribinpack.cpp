@@ -18,6 +18,16 @@
 //            (1 = en passant, 2 = castling written as king-takes-own-rook, 3 = promotion)
 // Every position BEFORE each move is emitted (Game::splat_to_bulletformat) with that move's eval (white-relative)
 // and the game result, through ChessBoard::from_raw (side-to-move relative).
+//
+// ViriFilter::Builtin (viribinpack.rs:178-187, `Filter::default()` in examples/simple.rs:84): the crate's own `Filter`
+// is restated too, from its published fields -- **parity unpinned** like the format. A position is dropped when
+//   ply < min_ply (ply = 2 * (fullmove - 1) + black to move, counted on through the game) | |eval| >= max_eval |
+//   pieces on the board < min_pieces | filter_tactical and the move captures (en passant too) or promotes |
+//   filter_check and the side to move is in check | filter_castling and the move castles |
+//   max_eval_incorrectness set and the eval points away from the game result by more than it (a draw: |eval|) |
+//   random_fen_skipping and a uniform draw < random_fen_skip_probability.
+// Default: min_ply 16, min_pieces 4, max_eval = the tablebase-win bound 20000, tactical and check filters on, the
+// rest off; `UNRESTRICTED` drops nothing. The crate's WDL-model filter (`wdl_filtered`, off by default) is not restated.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -35,6 +45,7 @@ namespace {
 struct ViriBoard {
     uint8_t sq[64];  // colour << 3 | type (0..5), 0xFF = empty
     bool black_to_move;
+    int fullmove;
 };
 
 void unpack(const uint8_t *p, ViriBoard *b, int16_t *eval, int *wdl) {
@@ -50,6 +61,9 @@ void unpack(const uint8_t *p, ViriBoard *b, int16_t *eval, int *wdl) {
         b->sq[s] = (uint8_t)((code & 8) | type);
     }
     b->black_to_move = (p[24] & 0x80) != 0;
+    uint16_t fullmove;
+    std::memcpy(&fullmove, p + 26, 2);
+    b->fullmove = fullmove;
     std::memcpy(eval, p + 28, 2);
     *wdl = p[30];
 }
@@ -102,12 +116,71 @@ bool to_record(const ViriBoard *b, int16_t eval_white, int wdl_white, uint8_t *o
     return true;
 }
 
+// Is `sq` attacked by a piece of colour `by` (0 white, 8 black)? Plain walks over the 64-square array.
+bool attacked(const ViriBoard *b, int sq, uint8_t by) {
+    const int r = sq >> 3, f = sq & 7;
+    auto at = [&](int rr, int ff) -> int { return (rr < 0 || rr > 7 || ff < 0 || ff > 7) ? -1 : b->sq[rr * 8 + ff]; };
+    const int pr = by ? r + 1 : r - 1;  // a white pawn attacks upwards: it stands one rank below its target
+    for (int df = -1; df <= 1; df += 2)
+        if (at(pr, f + df) == (by | 0)) return true;
+    static const int kn[8][2] = {{1, 2}, {2, 1}, {2, -1}, {1, -2}, {-1, -2}, {-2, -1}, {-2, 1}, {-1, 2}};
+    for (auto &d : kn)
+        if (at(r + d[0], f + d[1]) == (by | 1)) return true;
+    for (int dr = -1; dr <= 1; dr++)
+        for (int df = -1; df <= 1; df++) {
+            if (!dr && !df) continue;
+            if (at(r + dr, f + df) == (by | 5)) return true;
+            const bool diag = dr && df;
+            for (int rr = r + dr, ff = f + df;; rr += dr, ff += df) {
+                const int pc = at(rr, ff);
+                if (pc < 0) break;
+                if (pc == 0xFF) continue;
+                if (pc == (by | 4) || pc == (by | (diag ? 2 : 3))) return true;
+                break;
+            }
+        }
+    return false;
+}
+
+// Filter::should_filter of the crate, as restated in the header of this file: true = drop the position
+bool builtin_drops(const bt_viri_builtin_filter *f, const ViriBoard *b, uint16_t mv, int eval, int wdl_white, int ply,
+                   uint64_t *rng) {
+    if ((uint32_t)ply < f->min_ply) return true;
+    const uint32_t abs_eval = (uint32_t)(eval < 0 ? -eval : eval);
+    if (abs_eval >= f->max_eval) return true;
+    uint32_t pieces = 0;
+    int king = -1;
+    const uint8_t own = b->black_to_move ? 8 : 0;
+    for (int s = 0; s < 64; s++) {
+        if (b->sq[s] == 0xFF) continue;
+        pieces++;
+        if (b->sq[s] == (own | 5)) king = s;
+    }
+    if (pieces < f->min_pieces) return true;
+    const int to = (mv >> 6) & 63, flag = mv >> 14;
+    if (f->filter_tactical && (flag == 1 || flag == 3 || (flag != 2 && b->sq[to] != 0xFF))) return true;
+    if (f->filter_check && king >= 0 && attacked(b, king, own ^ 8)) return true;
+    if (f->filter_castling && flag == 2) return true;
+    if (f->max_eval_incorrectness != UINT32_MAX) {
+        const uint32_t err = wdl_white == 2 ? (eval < 0 ? abs_eval : 0) : wdl_white == 0 ? (eval > 0 ? abs_eval : 0) : abs_eval;
+        if (err > f->max_eval_incorrectness) return true;
+    }
+    if (f->random_fen_skipping) {
+        *rng ^= *rng << 13, *rng ^= *rng >> 7, *rng ^= *rng << 17;
+        if ((double)(*rng >> 11) * (1.0 / 9007199254740992.0) < f->random_fen_skip_probability) return true;
+    }
+    return false;
+}
+
 struct ViriSource {
     std::vector<std::string> paths;
     size_t buffer_positions;
     int threads;
     bt_viri_filter filter;
     void *user;
+    bool has_builtin = false;
+    bt_viri_builtin_filter builtin;
+    uint64_t skip_counter = 0;
     uint64_t rng;
     size_t file_idx = 0;
     FILE *fp = nullptr;
@@ -136,7 +209,7 @@ bool read_game(FILE *fp, std::vector<uint8_t> *games, std::vector<size_t> *start
     return true;
 }
 
-void splat(const uint8_t *g, const ViriSource *src, std::vector<uint8_t> *out, std::atomic<bool> *bad) {
+void splat(const uint8_t *g, const ViriSource *src, std::vector<uint8_t> *out, std::atomic<bool> *bad, uint64_t *skip_rng) {
     ViriBoard board;
     int16_t eval0;
     int wdl;
@@ -145,6 +218,7 @@ void splat(const uint8_t *g, const ViriSource *src, std::vector<uint8_t> *out, s
         bad->store(true);
         return;
     }
+    const int ply0 = 2 * (std::max(board.fullmove, 1) - 1) + (board.black_to_move ? 1 : 0);
     int ply = 0;
     for (const uint8_t *m = g + 32;; m += 4, ply++) {
         uint16_t mv;
@@ -156,8 +230,9 @@ void splat(const uint8_t *g, const ViriSource *src, std::vector<uint8_t> *out, s
             bad->store(true);
             return;
         }
-        if (!src->filter || src->filter(src->user, rec, mv, eval, (float)wdl / 2.0f, ply))
-            out->insert(out->end(), rec, rec + 32);
+        const bool keep = src->has_builtin ? !builtin_drops(&src->builtin, &board, mv, eval, wdl, ply0 + ply, skip_rng)
+                                           : (!src->filter || src->filter(src->user, rec, mv, eval, (float)wdl / 2.0f, ply));
+        if (keep) out->insert(out->end(), rec, rec + 32);
         if (board.sq[mv & 63] == 0xFF) {  // a move from an empty square: not a game of this format
             bad->store(true);
             return;
@@ -206,9 +281,15 @@ int refill(ViriSource *src, std::vector<uint8_t> *out) {
         std::vector<std::vector<uint8_t>> parts(workers);
         std::atomic<bool> bad(false);
         const size_t per = (starts.size() + workers - 1) / workers;
+        const uint64_t skip_base = src->skip_counter;
+        src->skip_counter += (uint64_t)workers;
         auto work = [&](int w) {
+            // (random skipping: one xorshift stream per worker and group of games, seeded by a counter the shuffle seed starts)
+            uint64_t z = skip_base + 0x9E3779B97F4A7C15ull * (uint64_t)(w + 1);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull, z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            uint64_t skip_rng = (z ^ (z >> 31)) | 1;
             for (size_t i = w * per; i < std::min(starts.size(), (w + 1) * per); i++)
-                splat(games.data() + starts[i], src, &parts[w], &bad);
+                splat(games.data() + starts[i], src, &parts[w], &bad, &skip_rng);
         };
         std::vector<std::thread> pool;
         for (int w = 1; w < workers; w++) pool.emplace_back(work, w);
@@ -245,9 +326,24 @@ int refill(ViriSource *src, std::vector<uint8_t> *out) {
 
 }  // namespace
 
+extern "C" void bt_viri_filter_default(bt_viri_builtin_filter *f) {
+    if (!f) return;
+    *f = bt_viri_builtin_filter{};
+    f->min_ply = 16, f->min_pieces = 4, f->max_eval = 20000;
+    f->filter_tactical = 1, f->filter_check = 1, f->filter_castling = 0;
+    f->max_eval_incorrectness = UINT32_MAX;
+    f->random_fen_skipping = 0, f->random_fen_skip_probability = 0.0;
+}
+
+extern "C" void bt_viri_filter_unrestricted(bt_viri_builtin_filter *f) {
+    if (!f) return;
+    *f = bt_viri_builtin_filter{};
+    f->max_eval = UINT32_MAX, f->max_eval_incorrectness = UINT32_MAX;
+}
+
 int bt_internal_viri_source(const char *const *paths, int n_paths, size_t buffer_size_mb, int threads,
-                            bt_viri_filter filter, void *user, uint64_t shuffle_seed,
-                            std::function<int(std::vector<uint8_t> &)> *out_refill) {
+                            bt_viri_filter filter, void *user, const bt_viri_builtin_filter *builtin,
+                            uint64_t shuffle_seed, std::function<int(std::vector<uint8_t> &)> *out_refill) {
     BT_REQUIRE(paths && n_paths > 0 && out_refill, "bt_reader_open_viribinpack: bad arguments");
     BT_REQUIRE(buffer_size_mb > 0, "bt_reader_open_viribinpack: buffer_size_mb must be positive");
     auto src = std::make_shared<ViriSource>();
@@ -263,13 +359,18 @@ int bt_internal_viri_source(const char *const *paths, int n_paths, size_t buffer
     src->buffer_positions = buffer_size_mb * 1024 * 1024 / 32 / 2;  // viribinpack.rs:50
     src->threads = threads > 0 ? threads : 1;
     src->filter = filter, src->user = user;
+    if (builtin) {
+        BT_REQUIRE(builtin->random_fen_skip_probability >= 0.0 && builtin->random_fen_skip_probability <= 1.0,
+                   "bt_reader_open_viribinpack: random_fen_skip_probability outside [0, 1]");
+        src->has_builtin = true, src->builtin = *builtin;
+    }
     if (shuffle_seed == 0) {  // SimpleRand::with_seed: microseconds since the epoch & 0xFFFF_FFFF (rng.rs:6-11)
         const auto us = std::chrono::duration_cast<std::chrono::microseconds>(
                             std::chrono::system_clock::now().time_since_epoch()).count();
         shuffle_seed = (uint64_t)us & 0xFFFFFFFFull;
         if (shuffle_seed == 0) shuffle_seed = 1;
     }
-    src->rng = shuffle_seed;
+    src->rng = shuffle_seed, src->skip_counter = shuffle_seed * 0x2545F4914F6CDD1Dull;
     *out_refill = [src](std::vector<uint8_t> &out) { return refill(src.get(), &out); };
     return BT_OK;
 }

@@ -113,6 +113,13 @@ COMM_ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c
 COMM_SCATTER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 
+class ViriBuiltinFilter(C.Structure):  # bt_viri_builtin_filter
+    _fields_ = [("min_ply", C.c_uint32), ("min_pieces", C.c_uint32), ("max_eval", C.c_uint32),
+                ("filter_tactical", C.c_int), ("filter_check", C.c_int), ("filter_castling", C.c_int),
+                ("max_eval_incorrectness", C.c_uint32), ("random_fen_skipping", C.c_int),
+                ("random_fen_skip_probability", C.c_double)]
+
+
 class CommHooks(C.Structure):
     _fields_ = [("all_reduce", COMM_ALLREDUCE_CB), ("reduce_scatter", COMM_SCATTER_CB), ("all_gather", COMM_SCATTER_CB),
                 ("user", C.c_void_p)]
@@ -153,6 +160,7 @@ SYMBOLS = [
     "bt_net_param_count", "bt_net_num_tensors", "bt_net_tensor_size", "bt_net_tensor_offset", "bt_net_create",
     "bt_net_destroy", "bt_net_params", "bt_net_grads", "bt_net_momentum", "bt_net_velocity", "bt_net_set_adamw",
     "bt_net_flat_size", "bt_net_max_batch", "bt_net_grads_owned", "bt_chessboard_from_str", "bt_measure_loader_throughput", "bt_reader_open_viribinpack", "bt_reader_open_sfbinpack",
+    "bt_reader_open_viribinpack_builtin", "bt_viri_filter_default", "bt_viri_filter_unrestricted",
     "bt_net_forward_backward", "bt_net_optimiser_step", "bt_net_optimiser_step_event", "bt_net_train_step", "bt_net_forward", "bt_net_hint_next_batch",
     "bt_input_init", "bt_input_num_inputs", "bt_input_max_active", "bt_map_batch", "bt_map_batch_device", "bt_map_batch_device_errors",
     "bt_net_init_weights_host", "bt_lr_at", "bt_wdl_at", "bt_reader_open", "bt_reader_next", "bt_reader_close",
@@ -191,6 +199,11 @@ def load():
     L.bt_reader_open_viribinpack.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p,
                                              C.c_uint64, C.POINTER(C.c_void_p)]
     L.bt_reader_open_sfbinpack.argtypes = L.bt_reader_open_viribinpack.argtypes
+    L.bt_reader_open_viribinpack_builtin.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.POINTER(ViriBuiltinFilter),
+                                                     C.c_uint64, C.POINTER(C.c_void_p)]
+    for f in ("bt_viri_filter_default", "bt_viri_filter_unrestricted"):
+        getattr(L, f).argtypes = [C.POINTER(ViriBuiltinFilter)]
+        getattr(L, f).restype = None
     L.bt_reader_next.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.bt_reader_close.argtypes = [C.c_void_p]
     L.bt_measure_loader_throughput.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]

@@ -9,7 +9,7 @@
 using namespace bullet_lib;
 
 int main(int argc, char **argv) {
-    // hyperparams to fiddle with
+    // the knobs of this run
     const int hl_size = 1024;
     const char *dataset_path = argc > 1 ? argv[1] : "data/baseline.data";
     const std::string out_dir = argc > 2 ? argv[2] : "checkpoints";
@@ -30,7 +30,7 @@ int main(int argc, char **argv) {
                 .inputs(inputs::ChessBucketsMirrored(BUCKET_LAYOUT))
                 .output_buckets(outputs::MaterialCount<NUM_OUTPUT_BUCKETS>{})
                 .save_format({
-                    // merge in the factoriser weights
+                    // what the engine reads: each bucket's columns with the shared (factoriser) columns added in
                     SavedFormat::id("l0w").merge_factoriser().round().quantise<int16_t>(255),
                     SavedFormat::id("l0b").round().quantise<int16_t>(255),
                     SavedFormat::id("l1w").round().quantise<int16_t>(64).transpose(),
@@ -38,25 +38,25 @@ int main(int argc, char **argv) {
                 })
                 .loss_fn([](auto output, auto target) { return output.sigmoid().squared_error(target); })
                 .build([&](ModelBuilder &builder, Node stm_inputs, Node ntm_inputs, Node output_buckets) {
-                    // input layer factoriser
+                    // l0f: the columns every king bucket shares
                     auto l0f = builder.new_weights("l0f", Shape{hl_size, 768}, InitSettings::Zeroed);
                     auto expanded_factoriser = l0f.repeat(NUM_INPUT_BUCKETS);
 
-                    // input layer weights
+                    // l0: one set of columns per king bucket, and the bias
                     auto l0 = builder.new_affine("l0", 768 * NUM_INPUT_BUCKETS, hl_size);
                     l0.weights = l0.weights + expanded_factoriser;
 
-                    // output layer weights
+                    // l1: one output per material bucket
                     auto l1 = builder.new_affine("l1", 2 * hl_size, NUM_OUTPUT_BUCKETS);
 
-                    // inference
+                    // forward pass
                     auto stm_hidden = l0.forward(stm_inputs).screlu();
                     auto ntm_hidden = l0.forward(ntm_inputs).screlu();
                     auto hidden_layer = stm_hidden.concat(ntm_hidden);
                     return l1.forward(hidden_layer).select(output_buckets);
                 });
 
-        // need to account for factoriser weight magnitudes
+        // the effective input weight is l0w + l0f, so each of the two gets half of the clipping range
         optimiser::AdamWParams stricter_clipping;
         stricter_clipping.max_weight = 0.99f, stricter_clipping.min_weight = -0.99f;
         trainer->optimiser.set_params_for_weight("l0w", stricter_clipping);

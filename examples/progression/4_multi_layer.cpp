@@ -9,7 +9,7 @@
 using namespace bullet_lib;
 
 int main(int argc, char **argv) {
-    // hyperparams to fiddle with
+    // the knobs of this run
     const int hl_size = 1024;
     const int l2_size = 16;
     const char *dataset_path = argc > 1 ? argv[1] : "data/baseline.data";
@@ -63,7 +63,7 @@ int main(int argc, char **argv) {
                     return l3.forward(hl3).select(output_buckets);
                 });
 
-        // need to account for factoriser weight magnitudes
+        // the effective input weight is l0w + l0f, so each of the two gets half of the clipping range
         optimiser::AdamWParams stricter_clipping;
         stricter_clipping.max_weight = 0.99f, stricter_clipping.min_weight = -0.99f;
         trainer->optimiser.set_params_for_weight("l0w", stricter_clipping);

@@ -19,27 +19,27 @@ int main(int argc, char **argv) {
     const int batches_per_superbatch = argc > 3 ? std::atoi(argv[3]) : 6104;
     try {
         auto trainer = ValueTrainerBuilder()
-                           // makes `ntm_inputs` available below
+                           // two perspectives: the builder callback below receives `ntm_inputs` too
                            .dual_perspective()
-                           // the default AdamW params include clipping to range [-1.98, 1.98]
+                           // AdamW with its defaults (weights are clipped to [-1.98, 1.98])
                            .optimiser(optimiser::AdamW{})
-                           // basic piece-square chessboard inputs
+                           // 768 inputs: piece type x colour x square
                            .inputs(inputs::Chess768{})
-                           // chosen such that inference may be efficiently implemented in-engine
+                           // QA and QB: scales an engine can run in 16-bit integers
                            .save_format({
                                SavedFormat::id("l0w").round().quantise<int16_t>(QA),
                                SavedFormat::id("l0b").round().quantise<int16_t>(QA),
                                SavedFormat::id("l1w").round().quantise<int16_t>(QB),
                                SavedFormat::id("l1b").round().quantise<int16_t>(QA * QB),
                            })
-                           // `target` == wdl * game_result + (1 - wdl) * sigmoid(search score in centipawns / SCALE)
+                           // the training target blends the game result (weight wdl) with sigmoid(score in centipawns / SCALE)
                            .loss_fn([](auto output, auto target) { return output.sigmoid().squared_error(target); })
-                           // the basic `(768 -> N)x2 -> 1` inference
+                           // (768 -> HIDDEN) per perspective, both halves concatenated, -> 1
                            .build([](ModelBuilder &builder, Node stm_inputs, Node ntm_inputs) {
-                               // weights
+                               // the two layers
                                auto l0 = builder.new_affine("l0", 768, HIDDEN_SIZE);
                                auto l1 = builder.new_affine("l1", 2 * HIDDEN_SIZE, 1);
-                               // inference
+                               // forward pass
                                auto stm_hidden = l0.forward(stm_inputs).screlu();
                                auto ntm_hidden = l0.forward(ntm_inputs).screlu();
                                auto hidden_layer = stm_hidden.concat(ntm_hidden);
@@ -55,15 +55,16 @@ int main(int argc, char **argv) {
             10,
         };
         LocalSettings settings{4, nullptr, "checkpoints", 64};
-        // loading from a Viriformat binpack (custom filters only: the crate's built-in `Filter` is not restated)
-        loader::ViriBinpackLoader data_loader_viri("data/run.binpack", 1024, 4);
+        // loading from a Viriformat binpack: the built-in filter with its default settings, or any function
+        // (board, move, eval, wdl) -> keep? in its place, as for SF binpacks
+        loader::ViriBinpackLoader data_loader_viri("data/run.binpack", 1024, 4, loader::Filter::standard());
         // loading from a SF binpack, with the filter of the reference's example
         loader::SfBinpackLoader data_loader_sf("data/test80.binpack", 1024, 4, [](const bt_sf_entry &entry) {
             return entry.ply >= 16 && !entry.in_check && std::abs(entry.score) <= 10000 && entry.move_type == 0 &&
                    entry.captured_piece == 7;
         });
         (void)data_loader_viri, (void)data_loader_sf;
-        // loading directly from a `BulletFormat` file
+        // ... or records already in bulletformat, read in file order
         loader::DirectSequentialDataLoader data_loader({data});
         trainer->run(schedule, settings, data_loader);
     } catch (const Error &e) {

@@ -497,11 +497,29 @@ int bt_reader_next(bt_reader *reader, void *dst_records, int count);
  * the move (viriformat encoding), its eval (white-relative centipawns), the game result for white (1.0 / 0.5 / 0.0)
  * and the ply inside the game; non-zero keeps the position; NULL keeps all. It runs on the worker threads.
  * shuffle_seed 0 = seeded from the clock like SimpleRand::with_seed. The wire format itself belongs to the
- * un-vendored crate viriformat 2.0.1 and is restated (parity unpinned, see csrc/viribinpack.cpp); the crate's
- * built-in `Filter` is not restated. Use the reader through bt_train_config.reader. */
+ * un-vendored crate viriformat 2.0.1 and is restated (parity unpinned, see csrc/viribinpack.cpp).
+ * Use the reader through bt_train_config.reader. */
 typedef int (*bt_viri_filter)(void *user, const void *chessboard32, uint16_t mv, int16_t eval, float wdl, int ply);
 int bt_reader_open_viribinpack(const char *const *paths, int n_paths, size_t buffer_size_mb, int threads,
                                bt_viri_filter filter, void *user, uint64_t shuffle_seed, bt_reader **reader);
+/* ViriFilter::Builtin (viribinpack.rs:17-27,178-187; `Filter::default()` in examples/simple.rs:84): the crate's own
+ * `Filter`, restated from its published fields (parity unpinned like the format; its WDL-model filter, off by default,
+ * is not restated). A position is DROPPED when: ply < min_ply (ply as in the FEN: 2 * (fullmove - 1) + black to move) |
+ * |eval| >= max_eval | fewer than min_pieces pieces | filter_tactical and its move captures or promotes |
+ * filter_check and the side to move is in check | filter_castling and its move castles | max_eval_incorrectness !=
+ * UINT32_MAX and the eval points away from the game's result by more than it (drawn game: |eval|) |
+ * random_fen_skipping and a uniform draw < random_fen_skip_probability. */
+typedef struct {
+    uint32_t min_ply, min_pieces, max_eval;
+    int filter_tactical, filter_check, filter_castling;
+    uint32_t max_eval_incorrectness;
+    int random_fen_skipping;
+    double random_fen_skip_probability;
+} bt_viri_builtin_filter;
+void bt_viri_filter_default(bt_viri_builtin_filter *filter);      /* Filter::default(): 16 / 4 / 20000, tactical + check on */
+void bt_viri_filter_unrestricted(bt_viri_builtin_filter *filter); /* Filter::UNRESTRICTED: drops nothing */
+int bt_reader_open_viribinpack_builtin(const char *const *paths, int n_paths, size_t buffer_size_mb, int threads,
+                                       const bt_viri_builtin_filter *filter, uint64_t shuffle_seed, bt_reader **reader);
 int bt_reader_open_sfbinpack(const char *const *paths, int n_paths, size_t buffer_size_mb, int threads,
                              bt_sf_filter filter, void *user, uint64_t shuffle_seed, bt_reader **reader);
 int bt_reader_close(bt_reader *reader);

@@ -230,9 +230,31 @@ struct InMemoryTextLoader {  // value/loader/text.rs
     explicit InMemoryTextLoader(const std::string &p) : paths{"text:" + p} {}
     bt_reader *open() const { return nullptr; }
 };
-// value/loader/viribinpack.rs. ViriFilter::Custom: (position as a 32-byte ChessBoard, move, eval, wdl) -> keep?
-// (the crate's built-in `Filter` is not restated, see csrc/viribinpack.cpp); an empty function keeps everything.
-using ViriFilter = std::function<bool(const uint8_t *chessboard, uint16_t mv, int16_t eval, float wdl)>;
+// value/loader/viribinpack.rs:17-27. ViriFilter is either the crate's built-in `Filter` (restated, parity unpinned: see
+// csrc/viribinpack.cpp; Filter::standard() is `Filter::default()`, Filter::unrestricted() is `Filter::UNRESTRICTED`) or
+// a custom function (position as a 32-byte ChessBoard, move, eval, wdl) -> keep?; an empty ViriFilter keeps everything.
+struct Filter : bt_viri_builtin_filter {
+    static Filter standard() {
+        Filter f;
+        bt_viri_filter_default(&f);
+        return f;
+    }
+    static Filter unrestricted() {
+        Filter f;
+        bt_viri_filter_unrestricted(&f);
+        return f;
+    }
+};
+using ViriCustomFilter = std::function<bool(const uint8_t *chessboard, uint16_t mv, int16_t eval, float wdl)>;
+struct ViriFilter {
+    bool builtin = false;
+    Filter filter{};
+    ViriCustomFilter custom;
+    ViriFilter() = default;
+    ViriFilter(const Filter &f) : builtin(true), filter(f) {}  // `impl From<Filter> for ViriFilter`
+    template <typename F, typename = decltype(std::declval<F>()((const uint8_t *)nullptr, uint16_t(), int16_t(), 0.0f))>
+    ViriFilter(F f) : custom(std::move(f)) {}
+};
 struct ViriBinpackLoader {
     std::vector<std::string> paths;
     size_t buffer_size_mb;
@@ -246,14 +268,18 @@ struct ViriBinpackLoader {
         l.paths = std::move(p);
         return l;
     }
-    bt_reader *open() const {  // `this` must outlive the reader (the filter is called through it)
+    bt_reader *open() const {  // `this` must outlive the reader (a custom filter is called through it)
         std::vector<const char *> c;
         for (const auto &p : paths) c.push_back(p.c_str());
         bt_reader *r = nullptr;
+        if (filter.builtin) {
+            check(bt_reader_open_viribinpack_builtin(c.data(), (int)c.size(), buffer_size_mb, threads, &filter.filter, 0, &r));
+            return r;
+        }
         bt_viri_filter cb = nullptr;
-        if (filter)
+        if (filter.custom)
             cb = [](void *u, const void *rec, uint16_t mv, int16_t eval, float wdl, int) -> int {
-                return static_cast<const ViriBinpackLoader *>(u)->filter(static_cast<const uint8_t *>(rec), mv, eval, wdl);
+                return static_cast<const ViriBinpackLoader *>(u)->filter.custom(static_cast<const uint8_t *>(rec), mv, eval, wdl);
             };
         check(bt_reader_open_viribinpack(c.data(), (int)c.size(), buffer_size_mb, threads, cb,
                                          const_cast<ViriBinpackLoader *>(this), 0, &r));

@@ -3,7 +3,9 @@ crates/bullet_lib/src/value/loader/viribinpack.rs). The reference holds no virif
 **parity unpinned**; what these tests pin is (a) the board replay -- every position of two hand-written games
 (en passant, both castlings written as king-takes-rook, a promotion, unmoved-rook codes) must equal the record the
 FEN text of that position parses to, (b) the reference's in-tree pieces: buffer size rule, xorshift Fisher-Yates
-shuffle (value/loader/rng.rs), looping over the files, the custom-filter contract."""
+shuffle (value/loader/rng.rs), looping over the files, the custom-filter contract, (c) the restated built-in `Filter`
+(ViriFilter::Builtin, viribinpack.rs:178-187) rule by rule on the same games plus one-move games that put the side to
+move in check by each kind of piece."""
 import ctypes as C
 import struct
 
@@ -42,7 +44,7 @@ GAME2 = [
 ]
 
 
-def pack_board(fen_board, black_to_move, castling_rooks, eval_, wdl):
+def pack_board(fen_board, black_to_move, castling_rooks, eval_, wdl, fullmove=1):
     """marlinformat PackedBoard of a position given as FEN board text"""
     sq_piece = {}
     rank, file = 7, 0
@@ -63,12 +65,12 @@ def pack_board(fen_board, black_to_move, castling_rooks, eval_, wdl):
         nibbles.append(code)
     nibbles += [0] * (32 - len(nibbles))
     pcs = bytes(nibbles[2 * i] | (nibbles[2 * i + 1] << 4) for i in range(16))
-    return struct.pack("<Q", occ) + pcs + struct.pack("<BBHhBB", (0x80 if black_to_move else 0) | 64, 0, 1, eval_, wdl, 0)
+    return struct.pack("<Q", occ) + pcs + struct.pack("<BBHhBB", (0x80 if black_to_move else 0) | 64, 0, fullmove, eval_, wdl, 0)
 
 
-def encode_game(game, castling_rooks, wdl, evals):
+def encode_game(game, castling_rooks, wdl, evals, fullmove=1):
     board, side = game[0][0].split()
-    out = pack_board(board, side == "b", castling_rooks, 0, wdl)
+    out = pack_board(board, side == "b", castling_rooks, 0, wdl, fullmove)
     for (_, frm, to, promo, flag), ev in zip(game, evals):
         out += struct.pack("<Hh", frm | (to << 6) | (promo << 12) | (flag << 14), ev)
     return out + b"\0\0\0\0"
@@ -165,3 +167,108 @@ def test_errors(tmp_path, binpack):
     h = open_reader([str(junk)], 1, 1, 1)
     assert L.bt_reader_next(h, out.ctypes.data, 4) != 0 and b"malformed" in L.bt_last_error()
     L.bt_reader_close(h)
+
+
+# ---- ViriFilter::Builtin: the crate's `Filter`, restated (parity unpinned; see csrc/viribinpack.cpp)
+CHECKS = [  # one-move games, black to move: (FEN board, in check?)
+    ("4k3/8/8/8/8/8/4R3/4K3 b", True),    # rook on the open file
+    ("4k3/4p3/8/8/8/8/4R3/4K3 b", False),  # the same file, blocked
+    ("4k3/3P4/8/8/8/8/8/4K3 b", True),    # pawn
+    ("4k3/4P3/8/8/8/8/8/4K3 b", False),   # a pawn straight ahead attacks nothing
+    ("4k3/8/3N4/8/8/8/8/4K3 b", True),    # knight
+    ("4k3/8/8/1B6/8/8/8/4K3 b", True),    # bishop on the long way round
+    ("4k3/8/8/1R6/8/8/8/4K3 b", False),   # a rook on that diagonal does not
+    ("4k3/8/8/8/Q7/8/8/4K3 b", True),     # queen, diagonal
+    ("3Kk3/8/8/8/8/8/8/8 b", True),       # (kings side by side: the walk sees the king too)
+]
+
+
+def builtin_reader(paths, filt, threads=2, seed=5):
+    h = C.c_void_p()
+    arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+    rc = L.bt_reader_open_viribinpack_builtin(arr, len(paths), 1, threads, C.byref(filt), seed, C.byref(h))
+    return rc, h
+
+
+def kept_set(paths, filt, n=4096):
+    rc, h = builtin_reader(paths, filt)
+    lib.check(rc)
+    got = np.zeros((n, 32), dtype=np.uint8)
+    lib.check(L.bt_reader_next(h, got.ctypes.data, n))
+    L.bt_reader_close(h)
+    return {r.tobytes() for r in got}
+
+
+def test_builtin_filter_rules(binpack, tmp_path):
+    paths, exp = binpack
+    n1 = len(GAME1)
+    rec = lambda idx: {exp[i].tobytes() for i in idx}
+    f = lib.ViriBuiltinFilter()
+    L.bt_viri_filter_unrestricted(C.byref(f))
+    assert kept_set(paths, f) == rec(range(len(exp)))  # Filter::UNRESTRICTED drops nothing
+    L.bt_viri_filter_default(C.byref(f))
+    assert (f.min_ply, f.min_pieces, f.max_eval, f.filter_tactical, f.filter_check, f.filter_castling) == (16, 4, 20000, 1, 1, 0)
+    assert f.max_eval_incorrectness == 0xFFFFFFFF and not f.random_fen_skipping
+    # GAME1 starts at fullmove 1, white to move: ply = index; GAME2 at fullmove 1, black to move: ply = 1 + index
+    f.min_ply = 3
+    quiet1 = [i for i, g in enumerate(GAME1) if i >= 3 and g[4] in (0, 2) and i != 5]  # 4: e.p., 5: Nxf6 -- tactical
+    # GAME2: 0 castles (kept, ply 1 < 3 though), 1 promotes, 2 Kxb8 captures, 3 has three pieces
+    assert kept_set(paths, f) == rec(quiet1)
+    f.min_ply = 0
+    assert kept_set(paths, f) == rec([i for i, g in enumerate(GAME1) if g[4] in (0, 2) and i != 5] + [n1])
+    f.filter_castling = 1
+    assert kept_set(paths, f) == rec([i for i, g in enumerate(GAME1) if g[4] == 0 and i != 5])
+    f.filter_castling, f.filter_tactical, f.min_pieces = 0, 0, 3
+    assert kept_set(paths, f) == rec(range(len(exp)))
+    f.min_pieces = 32  # only the positions before the first capture (the e.p. at index 4) have all 32 pieces
+    assert kept_set(paths, f) == rec(range(5))
+    # evals: EV1 = -30 ... 90 (white wins), EV2 = -500, 77, 0, 3 (black wins)
+    f.min_pieces, f.max_eval = 0, 77
+    assert kept_set(paths, f) == rec([i for i, e in enumerate(EV1) if abs(e) < 77] + [n1 + 2, n1 + 3])
+    f.max_eval, f.max_eval_incorrectness = 20000, 20
+    wrong1 = [i for i, e in enumerate(EV1) if e < -20]          # white won: a negative eval is wrong by |eval|
+    wrong2 = [n1 + i for i, e in enumerate(EV2) if e > 20]      # black won: a positive one
+    assert kept_set(paths, f) == rec(set(range(len(exp))) - set(wrong1) - set(wrong2))
+    # checks: nine one-move games (the king steps aside; three or four pieces on the board)
+    L.bt_viri_filter_unrestricted(C.byref(f))
+    f.filter_check = 1
+    games, want = b"", set()
+    for k, (fen, in_check) in enumerate(CHECKS):
+        g = [(fen, 60, 59 if k != 8 else 61, 0, 0)]
+        games += encode_game(g, set(), 1, [k])
+        if not in_check:
+            want.add(expected_records(g, 1, [k])[0].tobytes())
+    cf = tmp_path / "checks.vf"
+    cf.write_bytes(games)
+    assert kept_set([str(cf)], f) == want and len(want) == 3
+    # ply counts on from the header's fullmove
+    L.bt_viri_filter_unrestricted(C.byref(f))
+    f.min_ply = 21
+    late = tmp_path / "late.vf"
+    late.write_bytes(encode_game(GAME1, {0, 7, 56, 63}, 2, EV1, fullmove=10))  # plies 18 ... 30
+    assert kept_set([str(late)], f) == rec(range(3, n1))
+
+
+def test_builtin_filter_random_skipping(binpack):
+    paths, exp = binpack
+    f = lib.ViriBuiltinFilter()
+    L.bt_viri_filter_unrestricted(C.byref(f))
+    f.random_fen_skipping, f.random_fen_skip_probability = 1, 1.0
+    rc, h = builtin_reader(paths, f)
+    lib.check(rc)
+    out = np.zeros((4, 32), dtype=np.uint8)
+    assert L.bt_reader_next(h, out.ctypes.data, 4) != 0 and b"no position passes" in L.bt_last_error()
+    L.bt_reader_close(h)
+    f.random_fen_skip_probability = 0.5
+    rc, h = builtin_reader(paths, f, threads=1)
+    lib.check(rc)
+    n = 16384  # one shuffle buffer: whole epochs of 17 positions, about half of each kept
+    got = np.zeros((n, 32), dtype=np.uint8)
+    lib.check(L.bt_reader_next(h, got.ctypes.data, n))
+    L.bt_reader_close(h)
+    first = exp[0].tobytes()
+    share = sum(r.tobytes() == first for r in got) / (n / len(exp))
+    assert 0.8 < share < 1.2  # every position is kept with probability 1/2, so each is ~1/17 of the stream
+    f.random_fen_skip_probability = 1.5
+    rc, h = builtin_reader(paths, f)
+    assert rc != 0 and b"outside [0, 1]" in L.bt_last_error()
