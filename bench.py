@@ -271,6 +271,7 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
     lib.check(L.bt_event_record(uploaded[0], stream))
     counter = [0]
     waited = [0.0]
+    parts = [0.0, 0.0, 0.0]  # (hosttime aid: upload + map | hint + query | train step)
     landed = C.c_int(0)
 
     def step():
@@ -291,8 +292,11 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
                     waited[0] += time.perf_counter() - t_w
                 else:
                     L.bt_event_sync(consumed[nxt])
+            t_a = time.perf_counter()
             upload((i + 1) % n_distinct, nxt, copy)
             L.bt_event_record(uploaded[nxt], copy)
+            parts[0] += time.perf_counter() - t_a
+        t_b = time.perf_counter()
         if hints:  # multi-layer nets: its index structures are built during this step, once the upload has landed;
             # the single-layer net: the next step's index build is ordered behind this step without a fork packet
             net.hint_next(dev_batches[nxt], uploaded[nxt] if args.upload != "none" else None)
@@ -305,7 +309,10 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
             net.dp_step(comm, adj, lr, stream)  # exchange (grads + loss slot) and optimiser, replicas stay identical
             L.bt_event_record(consumed[cur], stream)
         else:  # fwd + bwd + AdamW; `consumed` rides on the last kernel's packet
+            t_c = time.perf_counter()
+            parts[1] += t_c - t_b
             net.train_step(dev_batches[cur], adj, lr, stream, consumed[cur])
+            parts[2] += time.perf_counter() - t_c
 
     def release():
         torch.cuda.synchronize()
@@ -352,14 +359,16 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
         lib.profile_start(steps * 2 + 64, only=[dom], every=SAMPLE)
     torch.cuda.synchronize()
     waited[0] = 0.0
+    parts[:] = [0.0, 0.0, 0.0]
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
     if "hosttime" in X:
-        print(f"host: {(t_host - waited[0]) / steps * 1e6:.1f} us busy, {waited[0] / steps * 1e6:.1f} us waiting per step",
-              file=sys.stderr)
+        print(f"host: {(t_host - waited[0]) / steps * 1e6:.1f} us busy, {waited[0] / steps * 1e6:.1f} us waiting per step; "
+              f"upload+map {parts[0] / steps * 1e6:.1f}, hint+query {parts[1] / steps * 1e6:.1f}, "
+              f"train step {parts[2] / steps * 1e6:.1f}", file=sys.stderr)
     if comm is not None:
         comm.barrier(stream)
     elapsed = time.perf_counter() - t0

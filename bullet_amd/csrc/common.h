@@ -139,7 +139,7 @@ int bt_internal_ft_forward_head(void *stream, const bt_ft_desc *d, const float *
 int bt_internal_ft_build_groups(void *stream, const bt_ft_desc *d, const int32_t *const *idx, void *workspace,
                                 size_t workspace_bytes, hipEvent_t done = nullptr);
 int bt_internal_ft_build_sorted(void *stream, const bt_ft_desc *d, const int32_t *const *idx, void *workspace,
-                                size_t workspace_bytes);
+                                size_t workspace_bytes, hipEvent_t done = nullptr);
 bool bt_internal_ft_grouped(const bt_ft_desc *d);
 // y = f(sum of the partials in order + bias[bucket]); sigmoid-MSE, its gradient, gz and loss partials like
 // bt_internal_dense_forward_loss

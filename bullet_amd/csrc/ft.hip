@@ -842,16 +842,6 @@ __device__ __forceinline__ int row_share(int v) {  // broadcast lane N of each 1
     return __builtin_amdgcn_update_dpp(v, v, 0x150 + N, 0xF, 0xF, true);
 }
 
-// The word held by slot J of the lane's own 8-lane group (fwd_gather_slot's map: a 16-lane row holds one group on lanes
-// 0-3 and 12-15 and one on lanes 4-11): two DPP row_share moves, each writing its group's two banks.
-template <int J>
-__device__ __forceinline__ uint32_t oct_group_bcast(uint32_t v) {
-    constexpr int LA = J < 4 ? J : 8 + J, LB = 4 + J;
-    int t = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x150 + LA, 0xF, 0x9, false);
-    t = __builtin_amdgcn_update_dpp(t, (int)v, 0x150 + LB, 0xF, 0x6, false);
-    return (uint32_t)t;
-}
-
 // 16 bytes at an LDS byte address (an integer, not a pointer derived from the dynamic LDS symbol: the compiler leaves an
 // add of the symbol's base, 0, on every address formed from the pointer)
 typedef float lds_f32x4 __attribute__((ext_vector_type(4)));
@@ -1550,21 +1540,11 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
             // row of a flush in front of the flagged row's own gathers, so that the flush never drains the wave's LDS
             // queue, was measured and is slower: +8 us.)
             float4 va0, va1, va2, va3, vb0, vb1, vb2, vb3;
-#ifdef BT_X_PARITY  // timing-only experiment: every gather forced onto the bank half of its group (wrong sums)
-            const uint32_t pmask = BT_X_PARITY ? 0xff00u : (0xff80u | (uint32_t)(rows_cap >> 30));
-            const uint32_t pm = BT_X_PARITY ? (uint32_t)(rg_e & 1) << 7 : (uint32_t)(rows_cap >> 30);
-#define ISSUE(V, Q)                                                                         \
-    V##0 = lds_load4((((Q).x) & pmask) | pm | lane16),                \
-    V##1 = lds_load4((((Q).x >> 16) & pmask) | pm | lane16),          \
-    V##2 = lds_load4((((Q).y) & pmask) | pm | lane16),                \
-    V##3 = lds_load4((((Q).y >> 16) & pmask) | pm | lane16)
-#else
 #define ISSUE(V, Q)                                          \
     V##0 = lds_load4(((Q).x & 0xff80u) | lane16),            \
     V##1 = lds_load4(((Q).x >> 16) + lane16),                \
     V##2 = lds_load4(((Q).y & 0xff80u) | lane16),            \
     V##3 = lds_load4(((Q).y >> 16) + lane16)
-#endif
             auto flush = [&](const uint2 q) {  // last row of an octet: the whole wave ends its runs here
                 const uint32_t kind = (q.x >> 1) & 3u, id = ((q.x >> 3) & 15u) | ((q.y & 127u) << 4);
                 if (kind == 1u) {
@@ -2404,7 +2384,7 @@ int bt_internal_ft_build_groups(void *stream, const bt_ft_desc *d, const int32_t
 }
 
 int bt_internal_ft_build_sorted(void *stream, const bt_ft_desc *d, const int32_t *const *idx, void *workspace,
-                                size_t workspace_bytes) {
+                                size_t workspace_bytes, hipEvent_t done) {
     if (int rc = ft_validate(d, "bt_ft_build_index")) return rc;
     BT_REQUIRE(idx && idx[0] && workspace, "bt_ft_build_index: null pointer");
     BT_REQUIRE(d->n_inputs == 1 || idx[1], "bt_ft_build_index: null index pointer for input 1");
@@ -2423,6 +2403,7 @@ int bt_internal_ft_build_sorted(void *stream, const bt_ft_desc *d, const int32_t
         uint2 *stream = reinterpret_cast<uint2 *>(ws + p.off_stream);
         uint8_t *meta = reinterpret_cast<uint8_t *>(ws + p.off_meta);
         const size_t olds = oct_index_lds_bytes(p.tc);
+        if (done) bt_attach_stop_event(BTK_FT_INDEX, done);  // (one launch follows: the event rides on it)
         if (p.grouped) {
             if (int rc = set_lds(ft_index_oct_kernel<true>, olds)) return rc;
             BT_LAUNCH(BTK_FT_INDEX, s, ft_index_oct_kernel<true>, dim3(p.nchunks), dim3(OCT_IDX_THREADS), olds, i0, i1,
@@ -2436,6 +2417,7 @@ int bt_internal_ft_build_sorted(void *stream, const bt_ft_desc *d, const int32_t
         return BT_OK;
     }
     // (a segment-grouped table fits the LDS kernels by definition, ft_plan: it took the branch above)
+    if (done) bt_attach_stop_event(BTK_FT_INDEX, done);
     BT_LAUNCH(BTK_FT_INDEX, s, ft_index_kernel, dim3(p.nchunks), dim3(threads), lds, i0, i1, d->batch, d->nnz, d->cols,
               p.chunks_per_input, p.fbits, sorted, offs);
     BT_LAUNCH_CHECK();

@@ -320,7 +320,11 @@ int prepare_next(bt_net *n, bool side_behind) {
     bt_ft_desc f = ft_desc(n, b->batch);
     const int32_t *idx[2] = {b->stm, b->nstm};
     if (!side_behind) BT_HIP(hipStreamWaitEvent(n->side, n->ev_fork, 0));
-    if (n->next_ready) BT_HIP(hipStreamWaitEvent(n->side, n->next_ready, 0));
+    // (the batch's ready event: usually long complete, and then not worth a wait packet)
+    if (n->next_ready && hipEventQuery(n->next_ready) != hipSuccess) {
+        (void)hipGetLastError();  // ("not ready" is an answer, not an error to be found by the next launch check)
+        BT_HIP(hipStreamWaitEvent(n->side, n->next_ready, 0));
+    }
     // The next step's FT forward needs the segment entry lists only; the bucket order and the sorted index are joined
     // later (before the layers): ev_next_groups rides on the lists' last kernel (a table that is not grouped has no lists
     // and no such event)
@@ -329,8 +333,8 @@ int prepare_next(bt_net *n, bool side_behind) {
         return rc;
     if (n->perm_alt && PermScope::perm_usable(n, b))
         if (int rc = bt_internal_bucket_perm(n->side, b->buckets, b->batch, n->d.num_buckets, n->perm_alt)) return rc;
-    if (int rc = bt_internal_ft_build_sorted(n->side, &f, idx, n->ft_ws_alt, n->ft_ws_bytes)) return rc;
-    BT_HIP(hipEventRecord(n->ev_next, n->side));
+    // (ev_next rides on the index kernel's packet)
+    if (int rc = bt_internal_ft_build_sorted(n->side, &f, idx, n->ft_ws_alt, n->ft_ws_bytes, n->ev_next)) return rc;
     n->prepared = true, n->prep_key = *b;
     return BT_OK;
 }
