@@ -10,7 +10,7 @@ import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_hbm"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/hbm_traffic.json"
-KERNELS = ["ft_fwd_lds", "ft_index_kernel", "ft_index_oct_kernel", "ft_bwd_oct", "ft_bwd_merge_head", "map_batch_kernel",
+KERNELS = ["ft_fwd_lds", "ft_fwd_decode_kernel", "ft_index_kernel", "ft_index_oct_kernel", "ft_bwd_oct", "ft_bwd_merge_head", "map_batch_kernel",
            "ft_bwd_merge", "head_finish_kernel", "dense_fwd_small",
            "dense_bwd_small_light", "dense_bwd_small", "sum_partials_seq4_kernel", "sum_partials4_kernel", "adamw_kernel",
            # the HalfKA multi-layer nets (bench.py --net cfg3 / cfg4)
