@@ -1257,6 +1257,8 @@ struct FtHeadGradSink {
 // result in registers and write it to the tile between the two barriers that separate chunks. So the global loads, the
 // activation derivative and the MFMAs of chunk c + 1 run beside the gathers of chunk c, on waves that never gather, the
 // tile needs no second buffer, and a reducing wave issues no vector-memory instruction but its own row fetches.
+// (Tried: a stream of a third of a reducer's share for each staging wave, reduced between forming one chunk and requesting
+// the next. The reduction's registers on top of the staging registers spill, and the kernel went from 99 to 117 us.)
 template <bool PAIR, bool FUSED, bool GRP, bool HDW>
 __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_out, const FtFusedSrc &fs,
                                                 const float *__restrict__ out, const float *__restrict__ saved,
@@ -1508,11 +1510,6 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
             qb0 = sp[(t1 + 0) * 8], qb1 = sp[(t1 + 1) * 8], qb2 = sp[(t1 + 2) * 8], qb3 = sp[(t1 + 3) * 8];
         };
         int n_r0 = 0, n_n = 0;  // row range of the chunk about to be reduced
-#ifdef BT_OCT_STATIC_PRIO
-        // the waves of a SIMD issue oldest-first: a fixed priority for the younger reducers keeps the three level
-        if (rw >= 8) __builtin_amdgcn_s_setprio(2);
-        else if (rw >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
         if (c_lo < c_hi) {
             load_meta(c_lo);
             n_r0 = __builtin_amdgcn_readfirstlane((int)m_r0), n_n = __builtin_amdgcn_readfirstlane((int)m_r1) - n_r0;
@@ -1538,7 +1535,7 @@ __device__ __forceinline__ void ft_bwd_oct_body(const float *__restrict__ grad_o
             // Two rows in flight: the gathers of row r + 1 are issued before the sums of row r are taken, so a wave keeps
             // eight ds_read_b128 outstanding and its adds and address arithmetic run under the LDS latency. (Reading the dW
             // row of a flush in front of the flagged row's own gathers, so that the flush never drains the wave's LDS
-            // queue, was measured and is slower: +8 us.)
+            // queue, was measured and is slower: +8 us; LDS float atomics for the flush: five times slower.)
             float4 va0, va1, va2, va3, vb0, vb1, vb2, vb3;
 #define ISSUE(V, Q)                                          \
     V##0 = lds_load4(((Q).x & 0xff80u) | lane16),            \
