@@ -1,5 +1,5 @@
 #!/bin/bash
-# the builder-run lines of profiles/r02/bench_lines.txt: other nets, occupancies, loaders and shard sizes
+# the builder-run lines of profiles/r03/bench_lines.txt (round 2: profiles/r02/): other nets, occupancies, loaders and shard sizes
 cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/bench_lines.txt
 : > $out
@@ -18,4 +18,9 @@ run --live-loader 400 --host-mapper &&
 run --upload mapped &&
 run --batch 2048 &&
 run --batch 4096 &&
-run --batch 8192
+run --batch 8192 &&
+for b in 2048 4096; do
+  echo "== host time per step, BENCH_X=hosttime bench.py --batch $b --no-profile" >> $out
+  BENCH_X=hosttime timeout -k 10 200 python3 bench.py --no-subrecords --no-cpu-baseline --no-profile --batch $b 2>&1 >/dev/null | grep "^host:" >> $out
+done
+tail -n 4 $out | cut -c 1-200
