@@ -19,6 +19,11 @@ int bt_internal_viri_source(const char *const *paths, int n_paths, size_t buffer
                             bt_viri_filter filter, void *user, const bt_viri_builtin_filter *builtin,
                             uint64_t shuffle_seed, std::function<int(std::vector<uint8_t> &)> *out_refill);
 
+// montybinpack.cpp: the same kind of source over montyformat games
+int bt_internal_monty_source(const char *const *paths, int n_paths, size_t buffer_size_mb, int threads,
+                             bt_monty_filter filter, void *user, uint64_t shuffle_seed,
+                             std::function<int(std::vector<uint8_t> &)> *out_refill);
+
 void bt_set_error(const char *fmt, ...);
 
 // comm.cpp: a communicator is either RCCL (rccl = the ncclComm_t, with a stream of its own for the collectives and

@@ -355,6 +355,19 @@ extern "C" int bt_reader_open_viribinpack_builtin(const char *const *paths, int 
     return BT_OK;
 }
 
+extern "C" int bt_reader_open_montybinpack(const char *const *paths, int n_paths, size_t buffer_size_mb, int threads,
+                                           bt_monty_filter filter, void *user, uint64_t shuffle_seed, bt_reader **out) {
+    BT_REQUIRE(out, "bt_reader_open_montybinpack: bad arguments");
+    bt_reader *r = new bt_reader();
+    if (int rc = bt_internal_monty_source(paths, n_paths, buffer_size_mb, threads, filter, user, shuffle_seed, &r->refill)) {
+        delete r;
+        return rc;
+    }
+    r->clock_seeded = shuffle_seed == 0;
+    *out = r;
+    return BT_OK;
+}
+
 extern "C" int bt_reader_open_sfbinpack(const char *const *paths, int n_paths, size_t buffer_size_mb, int threads,
                                         bt_sf_filter filter, void *user, uint64_t shuffle_seed, bt_reader **out) {
     BT_REQUIRE(out, "bt_reader_open_sfbinpack: bad arguments");

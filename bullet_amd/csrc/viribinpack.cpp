@@ -39,14 +39,11 @@
 #include <vector>
 
 #include "common.h"
+#include "game_source.h"
+
+typedef bt_game_board ViriBoard;
 
 namespace {
-
-struct ViriBoard {
-    uint8_t sq[64];  // colour << 3 | type (0..5), 0xFF = empty
-    bool black_to_move;
-    int fullmove;
-};
 
 void unpack(const uint8_t *p, ViriBoard *b, int16_t *eval, int *wdl) {
     uint64_t occ;
@@ -88,8 +85,10 @@ void make_move(ViriBoard *b, uint16_t mv) {
     b->black_to_move = !b->black_to_move;
 }
 
+}  // namespace
+
 // ChessBoard::from_raw(bbs, stm, score, result) of bulletformat (see host_inputs.cpp for the same convention)
-bool to_record(const ViriBoard *b, int16_t eval_white, int wdl_white, uint8_t *out) {
+bool bt_internal_board_to_record(const bt_game_board *b, int16_t eval_white, int wdl_white, uint8_t *out) {
     uint64_t occ = 0;
     uint8_t pcs[16] = {0};
     int n = 0, own_k = -1, opp_k = -1;
@@ -115,6 +114,8 @@ bool to_record(const ViriBoard *b, int16_t eval_white, int wdl_white, uint8_t *o
     out[29] = out[30] = out[31] = 0;
     return true;
 }
+
+namespace {
 
 // Is `sq` attacked by a piece of colour `by` (0 white, 8 black)? Plain walks over the 64-square array.
 bool attacked(const ViriBoard *b, int sq, uint8_t by) {
@@ -172,22 +173,11 @@ bool builtin_drops(const bt_viri_builtin_filter *f, const ViriBoard *b, uint16_t
     return false;
 }
 
-struct ViriSource {
-    std::vector<std::string> paths;
-    size_t buffer_positions;
-    int threads;
+struct ViriFilterSet {
     bt_viri_filter filter;
     void *user;
     bool has_builtin = false;
     bt_viri_builtin_filter builtin;
-    uint64_t skip_counter = 0;
-    uint64_t rng;
-    size_t file_idx = 0;
-    FILE *fp = nullptr;
-    std::vector<uint8_t> carry;  // positions decoded beyond the last full buffer
-    ~ViriSource() {
-        if (fp) std::fclose(fp);
-    }
 };
 
 // Game::deserialise_fast_into_buffer: header + moves up to and including the 4-byte terminator; false at EOF
@@ -209,7 +199,7 @@ bool read_game(FILE *fp, std::vector<uint8_t> *games, std::vector<size_t> *start
     return true;
 }
 
-void splat(const uint8_t *g, const ViriSource *src, std::vector<uint8_t> *out, std::atomic<bool> *bad, uint64_t *skip_rng) {
+void splat(const uint8_t *g, const ViriFilterSet *src, std::vector<uint8_t> *out, std::atomic<bool> *bad, uint64_t *skip_rng) {
     ViriBoard board;
     int16_t eval0;
     int wdl;
@@ -226,7 +216,7 @@ void splat(const uint8_t *g, const ViriSource *src, std::vector<uint8_t> *out, s
         std::memcpy(&mv, m, 2), std::memcpy(&eval, m + 2, 2);
         if (mv == 0 && eval == 0) break;
         uint8_t rec[32];
-        if (!to_record(&board, eval, wdl, rec)) {
+        if (!bt_internal_board_to_record(&board, eval, wdl, rec)) {
             bad->store(true);
             return;
         }
@@ -246,8 +236,10 @@ uint64_t xorshift(uint64_t *s) {  // SimpleRand::rng, value/loader/rng.rs:13-18
     return *s;
 }
 
-// One full shuffle buffer into `out`. 0 = ok.
-int refill(ViriSource *src, std::vector<uint8_t> *out) {
+}  // namespace
+
+// One full shuffle buffer into `out`. 0 = ok. (shared with montybinpack.cpp: the same pipeline around another decoder)
+int bt_internal_game_refill(bt_game_source *src, std::vector<uint8_t> *out) {
     const size_t want = src->buffer_positions * 32;
     out->clear();
     out->swap(src->carry);
@@ -266,7 +258,7 @@ int refill(ViriSource *src, std::vector<uint8_t> *out) {
                     return BT_ERR_IO;
                 }
             }
-            if (!read_game(src->fp, &games, &starts)) {  // end of this file: next one, round and round (:73-94)
+            if (!src->read_game(src->fp, &games, &starts)) {  // end of this file: next one, round and round (:73-94)
                 std::fclose(src->fp);
                 src->fp = nullptr;
                 src->file_idx = (src->file_idx + 1) % src->paths.size();
@@ -289,20 +281,20 @@ int refill(ViriSource *src, std::vector<uint8_t> *out) {
             z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull, z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
             uint64_t skip_rng = (z ^ (z >> 31)) | 1;
             for (size_t i = w * per; i < std::min(starts.size(), (w + 1) * per); i++)
-                splat(games.data() + starts[i], src, &parts[w], &bad, &skip_rng);
+                src->splat(games.data() + starts[i], &parts[w], &bad, &skip_rng);
         };
         std::vector<std::thread> pool;
         for (int w = 1; w < workers; w++) pool.emplace_back(work, w);
         work(0);
         for (auto &t : pool) t.join();
         if (bad.load()) {
-            bt_set_error("viribinpack: malformed game in %s", src->paths[src->file_idx].c_str());
+            bt_set_error("%s: malformed game in %s", src->what, src->paths[src->file_idx].c_str());
             return BT_ERR_IO;
         }
         for (auto &p : parts) out->insert(out->end(), p.begin(), p.end());
         if (wrapped) {
             if (out->size() == size_at_wrap) {
-                bt_set_error("viribinpack: no position passes the filter (or the files hold no games)");
+                bt_set_error("%s: no position passes the filter (or the files hold no games)", src->what);
                 return BT_ERR_IO;
             }
             size_at_wrap = out->size();
@@ -324,7 +316,30 @@ int refill(ViriSource *src, std::vector<uint8_t> *out) {
     return BT_OK;
 }
 
-}  // namespace
+int bt_internal_game_source_open(bt_game_source *src, const char *const *paths, int n_paths, size_t buffer_size_mb,
+                                 int threads, uint64_t shuffle_seed, const char *who) {
+    BT_REQUIRE(paths && n_paths > 0, "%s: bad arguments", who);
+    BT_REQUIRE(buffer_size_mb > 0, "%s: buffer_size_mb must be positive", who);
+    for (int i = 0; i < n_paths; i++) {
+        FILE *f = std::fopen(paths[i], "rb");
+        if (!f) {
+            bt_set_error("File not found: %s", paths[i]);
+            return BT_ERR_IO;
+        }
+        std::fclose(f);
+        src->paths.push_back(paths[i]);
+    }
+    src->buffer_positions = buffer_size_mb * 1024 * 1024 / 32 / 2;  // viribinpack.rs:50, montybinpack.rs:35
+    src->threads = threads > 0 ? threads : 1;
+    if (shuffle_seed == 0) {  // SimpleRand::with_seed: microseconds since the epoch & 0xFFFF_FFFF (rng.rs:6-11)
+        const auto us = std::chrono::duration_cast<std::chrono::microseconds>(
+                            std::chrono::system_clock::now().time_since_epoch()).count();
+        shuffle_seed = (uint64_t)us & 0xFFFFFFFFull;
+        if (shuffle_seed == 0) shuffle_seed = 1;
+    }
+    src->rng = shuffle_seed, src->skip_counter = shuffle_seed * 0x2545F4914F6CDD1Dull;
+    return BT_OK;
+}
 
 extern "C" void bt_viri_filter_default(bt_viri_builtin_filter *f) {
     if (!f) return;
@@ -344,33 +359,23 @@ extern "C" void bt_viri_filter_unrestricted(bt_viri_builtin_filter *f) {
 int bt_internal_viri_source(const char *const *paths, int n_paths, size_t buffer_size_mb, int threads,
                             bt_viri_filter filter, void *user, const bt_viri_builtin_filter *builtin,
                             uint64_t shuffle_seed, std::function<int(std::vector<uint8_t> &)> *out_refill) {
-    BT_REQUIRE(paths && n_paths > 0 && out_refill, "bt_reader_open_viribinpack: bad arguments");
-    BT_REQUIRE(buffer_size_mb > 0, "bt_reader_open_viribinpack: buffer_size_mb must be positive");
-    auto src = std::make_shared<ViriSource>();
-    for (int i = 0; i < n_paths; i++) {
-        FILE *f = std::fopen(paths[i], "rb");
-        if (!f) {
-            bt_set_error("File not found: %s", paths[i]);
-            return BT_ERR_IO;
-        }
-        std::fclose(f);
-        src->paths.push_back(paths[i]);
-    }
-    src->buffer_positions = buffer_size_mb * 1024 * 1024 / 32 / 2;  // viribinpack.rs:50
-    src->threads = threads > 0 ? threads : 1;
-    src->filter = filter, src->user = user;
+    BT_REQUIRE(out_refill, "bt_reader_open_viribinpack: bad arguments");
+    auto src = std::make_shared<bt_game_source>();
+    if (int rc = bt_internal_game_source_open(src.get(), paths, n_paths, buffer_size_mb, threads, shuffle_seed,
+                                              "bt_reader_open_viribinpack"))
+        return rc;
+    ViriFilterSet fs;
+    fs.filter = filter, fs.user = user;
     if (builtin) {
         BT_REQUIRE(builtin->random_fen_skip_probability >= 0.0 && builtin->random_fen_skip_probability <= 1.0,
                    "bt_reader_open_viribinpack: random_fen_skip_probability outside [0, 1]");
-        src->has_builtin = true, src->builtin = *builtin;
+        fs.has_builtin = true, fs.builtin = *builtin;
     }
-    if (shuffle_seed == 0) {  // SimpleRand::with_seed: microseconds since the epoch & 0xFFFF_FFFF (rng.rs:6-11)
-        const auto us = std::chrono::duration_cast<std::chrono::microseconds>(
-                            std::chrono::system_clock::now().time_since_epoch()).count();
-        shuffle_seed = (uint64_t)us & 0xFFFFFFFFull;
-        if (shuffle_seed == 0) shuffle_seed = 1;
-    }
-    src->rng = shuffle_seed, src->skip_counter = shuffle_seed * 0x2545F4914F6CDD1Dull;
-    *out_refill = [src](std::vector<uint8_t> &out) { return refill(src.get(), &out); };
+    src->what = "viribinpack";
+    src->read_game = read_game;
+    src->splat = [fs](const uint8_t *g, std::vector<uint8_t> *out, std::atomic<bool> *bad, uint64_t *skip_rng) {
+        splat(g, &fs, out, bad, skip_rng);
+    };
+    *out_refill = [src](std::vector<uint8_t> &out) { return bt_internal_game_refill(src.get(), &out); };
     return BT_OK;
 }

@@ -160,7 +160,7 @@ SYMBOLS = [
     "bt_net_param_count", "bt_net_num_tensors", "bt_net_tensor_size", "bt_net_tensor_offset", "bt_net_create",
     "bt_net_destroy", "bt_net_params", "bt_net_grads", "bt_net_momentum", "bt_net_velocity", "bt_net_set_adamw",
     "bt_net_flat_size", "bt_net_max_batch", "bt_net_grads_owned", "bt_chessboard_from_str", "bt_measure_loader_throughput", "bt_reader_open_viribinpack", "bt_reader_open_sfbinpack",
-    "bt_reader_open_viribinpack_builtin", "bt_viri_filter_default", "bt_viri_filter_unrestricted",
+    "bt_reader_open_viribinpack_builtin", "bt_viri_filter_default", "bt_viri_filter_unrestricted", "bt_reader_open_montybinpack",
     "bt_net_forward_backward", "bt_net_optimiser_step", "bt_net_optimiser_step_event", "bt_net_train_step", "bt_net_forward", "bt_net_hint_next_batch",
     "bt_input_init", "bt_input_num_inputs", "bt_input_max_active", "bt_map_batch", "bt_map_batch_device", "bt_map_batch_device_errors",
     "bt_net_init_weights_host", "bt_lr_at", "bt_wdl_at", "bt_reader_open", "bt_reader_next", "bt_reader_close",
@@ -199,6 +199,7 @@ def load():
     L.bt_reader_open_viribinpack.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p,
                                              C.c_uint64, C.POINTER(C.c_void_p)]
     L.bt_reader_open_sfbinpack.argtypes = L.bt_reader_open_viribinpack.argtypes
+    L.bt_reader_open_montybinpack.argtypes = L.bt_reader_open_viribinpack.argtypes
     L.bt_reader_open_viribinpack_builtin.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.POINTER(ViriBuiltinFilter),
                                                      C.c_uint64, C.POINTER(C.c_void_p)]
     for f in ("bt_viri_filter_default", "bt_viri_filter_unrestricted"):

@@ -522,6 +522,16 @@ int bt_reader_open_viribinpack_builtin(const char *const *paths, int n_paths, si
                                        const bt_viri_builtin_filter *filter, uint64_t shuffle_seed, bt_reader **reader);
 int bt_reader_open_sfbinpack(const char *const *paths, int n_paths, size_t buffer_size_mb, int threads,
                              bt_sf_filter filter, void *user, uint64_t shuffle_seed, bt_reader **reader);
+/* MontyBinpackLoader (value/loader/montybinpack.rs:17-186): games in montyformat (`MontyValueFormat`) replayed into
+ * bulletformat positions, the same pipeline and shuffle buffer as the viriformat loader. The filter is the reference's
+ * `Fn(&Position, Move, i16, f32) -> bool` (montybinpack.rs:18,169): called for every position before its move with the
+ * position as a 32-byte ChessBoard, the move (montyformat encoding: from << 10 | to << 4 | flag), its score
+ * (white-relative) and the game result for white (1.0 / 0.5 / 0.0); non-zero keeps the position, NULL keeps all. The wire
+ * format and the move maker belong to the un-vendored crate montyformat 0.9.2 and are restated (parity unpinned, see
+ * csrc/montybinpack.cpp). */
+typedef int (*bt_monty_filter)(void *user, const void *chessboard32, uint16_t mv, int16_t score, float result);
+int bt_reader_open_montybinpack(const char *const *paths, int n_paths, size_t buffer_size_mb, int threads,
+                                bt_monty_filter filter, void *user, uint64_t shuffle_seed, bt_reader **reader);
 int bt_reader_close(bt_reader *reader);
 
 /* run::train (run.rs:75-265) for one device: loader thread (reader -> bt_map_batch into a pinned ring) ->

@@ -314,6 +314,36 @@ struct SfBinpackLoader {
         return r;
     }
 };
+// value/loader/montybinpack.rs. The filter is the reference's `Fn(&Position, Move, i16, f32) -> bool`: (position as a
+// 32-byte ChessBoard, move in montyformat's encoding, score, game result) -> keep?; an empty function keeps everything.
+using MontyFilter = std::function<bool(const uint8_t *chessboard, uint16_t mv, int16_t score, float result)>;
+struct MontyBinpackLoader {
+    std::vector<std::string> paths;
+    size_t buffer_size_mb;
+    int threads;
+    MontyFilter filter;
+    MontyBinpackLoader(const std::string &path, size_t buffer_mb, int threads_, MontyFilter f = {})
+        : paths{path}, buffer_size_mb(buffer_mb), threads(threads_), filter(std::move(f)) {}
+    static MontyBinpackLoader new_concat_multiple(std::vector<std::string> p, size_t buffer_mb, int threads_,
+                                                  MontyFilter f = {}) {
+        MontyBinpackLoader l(p.at(0), buffer_mb, threads_, std::move(f));
+        l.paths = std::move(p);
+        return l;
+    }
+    bt_reader *open() const {  // `this` must outlive the reader (the filter is called through it)
+        std::vector<const char *> c;
+        for (const auto &p : paths) c.push_back(p.c_str());
+        bt_reader *r = nullptr;
+        bt_monty_filter cb = nullptr;
+        if (filter)
+            cb = [](void *u, const void *rec, uint16_t mv, int16_t score, float result) -> int {
+                return static_cast<const MontyBinpackLoader *>(u)->filter(static_cast<const uint8_t *>(rec), mv, score, result);
+            };
+        check(bt_reader_open_montybinpack(c.data(), (int)c.size(), buffer_size_mb, threads, cb,
+                                          const_cast<MontyBinpackLoader *>(this), 0, &r));
+        return r;
+    }
+};
 }  // namespace loader
 
 // ------------------------------------------------------------------------------------------ trainer::save

@@ -15,10 +15,12 @@ int main(int argc, char **argv) {
     std::mt19937_64 rng(123);
     int ok = 0, bad = 0;
     auto slurp = [](const char *p) { std::vector<uint8_t> v; FILE *f = fopen(p, "rb"); int c; while ((c = fgetc(f)) != EOF) v.push_back((uint8_t)c); fclose(f); return v; };
-    const std::vector<uint8_t> seed_sf = slurp("/tmp/bt_fuzz/seed.binpack"), seed_vf = slurp("/tmp/bt_fuzz/seed.vf");
-    for (int trial = 0; trial < 6000; trial++) {
-        const bool sf = trial & 1;
-        std::vector<uint8_t> body = sf ? seed_sf : seed_vf;
+    const std::vector<uint8_t> seed_sf = slurp("/tmp/bt_fuzz/seed.binpack"), seed_vf = slurp("/tmp/bt_fuzz/seed.vf"),
+                               seed_mf = slurp("/tmp/bt_fuzz/seed.mf");
+    for (int trial = 0; trial < 9000; trial++) {
+        const int which = trial % 3;  // 0 viriformat, 1 Stockfish binpack, 2 montyformat
+        const bool sf = which == 1;
+        std::vector<uint8_t> body = sf ? seed_sf : which == 2 ? seed_mf : seed_vf;
         const int flips = trial < 2 ? 0 : 1 + rng() % 4;
         for (int i = 0; i < flips; i++) {
             size_t at = rng() % body.size();
@@ -31,8 +33,12 @@ int main(int argc, char **argv) {
         fclose(f);
         const char *paths[1] = {path.c_str()};
         std::function<int(std::vector<uint8_t> &)> refill;
+        bt_viri_builtin_filter vf;
+        bt_viri_filter_default(&vf);
+        vf.min_ply = 0;
         int rc = sf ? bt_internal_sf_source(paths, 1, 1, 2, nullptr, nullptr, 1, &refill)
-                    : bt_internal_viri_source(paths, 1, 1, 2, nullptr, nullptr, 1, &refill);
+                 : which == 2 ? bt_internal_monty_source(paths, 1, 1, 2, nullptr, nullptr, 1, &refill)
+                              : bt_internal_viri_source(paths, 1, 1, 2, nullptr, nullptr, (trial & 8) ? &vf : nullptr, 1, &refill);
         if (rc) { bad++; continue; }
         std::vector<uint8_t> out;
         rc = refill(out);
