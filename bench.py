@@ -209,6 +209,8 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
         host_packs.append(hp)
 
     net = lib.Net(lib.make_net_desc(**netcfg), B)
+    graphs = args.graphs == "on"
+    lib.check(L.bt_net_use_graphs(net.h, int(graphs)))
     if net_name == "cfg2":  # random-init weights of the architecture: Normal(0, sqrt(2/in)), same on all ranks
         rng = np.random.default_rng(1234)
         init = []
@@ -355,7 +357,10 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
     SAMPLE = 8 if steps >= 64 else max(1, -(-steps // 3))  # (a short run gets three timed launches: each costs ~10 us)
     if comm is not None:
         comm.barrier(stream)
-    if profile and dom:
+    # Graph steps carry no per-kernel timestamps (and an armed profiler makes the library run steps the ordinary way):
+    # with graphs on, the timed region runs unprofiled and the dominant kernel is timed over as many ordinary steps
+    # right after it, outside the timed region.
+    if profile and dom and not graphs:
         lib.profile_start(steps * 2 + 64, only=[dom], every=SAMPLE)
     torch.cuda.synchronize()
     waited[0] = 0.0
@@ -372,10 +377,17 @@ def run_case(args, net_name, occupancy, B, global_batch, rank, comm, steps, warm
     if comm is not None:
         comm.barrier(stream)
     elapsed = time.perf_counter() - t0
-    kern = lib.profile_stop() if (profile and dom) else {}
+    kern = lib.profile_stop() if (profile and dom and not graphs) else {}
+    n_graph = L.bt_net_graph_launches(net.h)
+    if profile and dom and graphs:
+        lib.profile_start(steps * 2 + 64, only=[dom], every=SAMPLE)
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        kern = lib.profile_stop()
     res = {"elapsed": elapsed, "loss": net.loss.item() / global_batch, "nbar": float(nbar), "warm": warm, "dom": dom,
            "kern": kern.get(dom) if dom else None, "sample": SAMPLE, "netcfg": netcfg, "workload": workload,
-           "first_batch": first, "net": net, "idesc": idesc, "release": release}
+           "first_batch": first, "net": net, "idesc": idesc, "release": release, "graph_steps": n_graph}
     if comm is not None and comm.world > 1:  # the exchange alone, same buffers, back to back
         reps = 50
         torch.cuda.synchronize()
@@ -404,7 +416,11 @@ def case_record(res, B, global_batch, steps, warmup, net_name, with_kernels=True
         rl = roofline_record(res["dom"], c, t, res["sample"], steps, B, res["nbar"], res["netcfg"],
                              res["elapsed"] / steps, traffic_table(net_name))
         if rl:
+            if res.get("graph_steps"):
+                rl["timed"] = "over as many ordinary steps right after the timed region (steps replayed as hipGraphs carry no per-kernel timestamps)"
             out["roofline"] = rl
+    if res.get("graph_steps"):
+        out["graph_steps"] = res["graph_steps"]  # steps of warm-up + timed region that ran as one hipGraph launch
     return out
 
 
@@ -432,6 +448,11 @@ def main():
                     help="do not announce the next batch (bt_net_hint_next_batch): multi-layer nets then build its index "
                          "structures on the step's own critical path, the single-layer net forks its side stream "
                          "with an event packet per step")
+    ap.add_argument("--graphs", choices=("on", "off"), default="off",
+                    help="bt_net_use_graphs: steady-state steps replayed as hipGraphs. Off by default: measured on this "
+                         "stack (ROCm 7.2) one hipGraphLaunch of the step's six kernels in two branches costs the host "
+                         "~100 us against ~39 us for the ten ordinary calls (profiles/r03/bench_lines.txt), so it loses "
+                         "at every batch size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-subrecords", action="store_true",
                     help="only the main workload: no fixture_occupancy / halfka (N = 1) or weak (N > 1) sub-records")

@@ -89,6 +89,7 @@ enum BtKernelId {
 };
 int bt_prof_register(const char *kernel_expr);  // -> profiler id of the kernel spelled `kernel_expr`
 bool bt_prof_enabled(int id);
+bool bt_prof_active();  // the calling thread's profiler is armed (bt_profile_start .. bt_profile_stop)
 void bt_prof_record(int id, hipStream_t s, bool begin);
 struct BtProfScope {
     int id;
@@ -111,11 +112,17 @@ hipEvent_t bt_take_stop_event(int kernel_id);
 // next kernel (bracketing with hipEventRecord measured the waits in front of a kernel as well). A launch that also
 // carries a completion event records that one separately while it is being timed.
 bool bt_prof_take_pair(int id, hipEvent_t *a, hipEvent_t *b);
+// While the calling thread captures a step into a hipGraph (net.hip), launches are plain: no timing, and a completion
+// event that would ride on the packet is dropped (the capturing code records it after the graph's launch instead).
+bool bt_capturing();
+void bt_set_capturing(bool on);
 #define BT_LAUNCH(id, stream, kernel, grid, block, lds, ...)                                        \
     do {                                                                                            \
         static const int pk_ = bt_prof_register(#kernel);                                           \
+        const bool cap_ = bt_capturing();                                                           \
         hipEvent_t stop_ev_ = bt_take_stop_event(id), pa_ = nullptr, pb_ = nullptr;                 \
-        const bool prof_ = bt_prof_enabled(pk_);                                                    \
+        if (cap_) stop_ev_ = nullptr;                                                               \
+        const bool prof_ = !cap_ && bt_prof_enabled(pk_);                                           \
         if (prof_ && bt_prof_take_pair(pk_, &pa_, &pb_)) {                                          \
             hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, pa_, pb_, 0, __VA_ARGS__);      \
             if (stop_ev_) (void)hipEventRecord(stop_ev_, stream); /* timed: the completion event gets its own packet */ \
@@ -242,6 +249,7 @@ bool bt_internal_dense_forward_loss_ok(const bt_dense_desc *d);
 
 // allocates the second index-buffer set of bt_net_hint_next_batch now (instead of on the first hint)
 int bt_internal_net_enable_hints(bt_net *net);
+void bt_internal_net_drop_graphs(bt_net *net);
 
 // ---- device-side activation helpers (semantics: dfo.rs:47-103, pointwise.rs:54-139) ----
 __device__ __forceinline__ float bt_act_fwd(int act, float v) {

@@ -55,6 +55,19 @@ struct bt_net {
     // this step needs no fork packet on `s`. Null after anything else was queued that reads the index workspace.
     hipEvent_t ev_step = nullptr, prev_done = nullptr;
     hipEvent_t next_ready = nullptr, ev_next = nullptr, ev_next_groups = nullptr;
+    // bt_net_use_graphs: steady-state steps of the single-layer fused path (batch prepared ahead, next batch hinted) are
+    // captured once per (batch tensors, next batch tensors, buffer set, stream, ...) and replayed as one hipGraph launch
+    struct StepGraph {
+        bt_batch cur, next;
+        const void *loss, *adj, *lr, *ws;
+        hipStream_t stream;
+        bool with_opt, stepped;
+        hipGraphExec_t exec;
+    };
+    bool use_graphs = false, capturing = false, cap_ok = false, last_graph = false;
+    hipEvent_t ev_cap_join = nullptr;
+    std::vector<StepGraph> graphs;
+    int graph_launches = 0;
 };
 
 namespace {
@@ -321,7 +334,7 @@ int prepare_next(bt_net *n, bool side_behind) {
     const int32_t *idx[2] = {b->stm, b->nstm};
     if (!side_behind) BT_HIP(hipStreamWaitEvent(n->side, n->ev_fork, 0));
     // (the batch's ready event: usually long complete, and then not worth a wait packet)
-    if (n->next_ready && hipEventQuery(n->next_ready) != hipSuccess) {
+    if (n->next_ready && !n->capturing && hipEventQuery(n->next_ready) != hipSuccess) {
         (void)hipGetLastError();  // ("not ready" is an answer, not an error to be found by the next launch check)
         BT_HIP(hipStreamWaitEvent(n->side, n->next_ready, 0));
     }
@@ -342,6 +355,13 @@ int prepare_next(bt_net *n, bool side_behind) {
 const float *net_output(const bt_net *n) { return has_skip(&n->d) ? n->yfin : n->a[n->d.n_dense - 1]; }
 
 }  // namespace
+
+// captured steps hold kernel arguments by value (optimiser settings among them): whoever changes those drops the graphs
+void bt_internal_net_drop_graphs(bt_net *n) {
+    for (auto &g : n->graphs) (void)hipGraphExecDestroy(g.exec);
+    n->graphs.clear();
+    n->last_graph = false;
+}
 
 int bt_internal_net_enable_hints(bt_net *n) {
     if (n->ft_ws_alt) return BT_OK;
@@ -466,7 +486,8 @@ int bt_net_create(const bt_net_desc *desc, int max_batch, float *ext_params, flo
         hipEventCreateWithFlags(&n->ev_sums, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&n->ev_step, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&n->ev_next, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&n->ev_next_groups, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&n->ev_next_groups, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&n->ev_cap_join, hipEventDisableTiming) != hipSuccess) {
         bt_set_error("bt_net_create: could not create the side stream / events");
         return fail(BT_ERR_HIP);
     }
@@ -492,6 +513,8 @@ int bt_net_destroy(bt_net *n) {
     if (n->ev_dfork) (void)hipEventDestroy(n->ev_dfork);
     if (n->ev_sums) (void)hipEventDestroy(n->ev_sums);
     if (n->ev_step) (void)hipEventDestroy(n->ev_step);
+    if (n->ev_cap_join) (void)hipEventDestroy(n->ev_cap_join);
+    for (auto &g : n->graphs) (void)hipGraphExecDestroy(g.exec);
     bt_free(n->ft_ws_alt), bt_free(n->perm_alt);
     if (n->side) (void)hipStreamDestroy(n->side);
     delete n;
@@ -511,6 +534,7 @@ int bt_net_set_adamw(bt_net *n, int t, float decay, float beta1, float beta2, fl
     BT_REQUIRE(max_w >= min_w, "Invalid clipping: %g >= %g", min_w, max_w);  // adam.rs:259-263
     bt_adamw_tensor &a = n->adam[t];
     a.decay = decay, a.beta1 = beta1, a.beta2 = beta2, a.min_weight = min_w, a.max_weight = max_w;
+    bt_internal_net_drop_graphs(n);
     return BT_OK;
 }
 
@@ -557,7 +581,97 @@ int bt_net_train_step(bt_net *n, void *stream, const bt_batch *b, float *loss_su
 }
 
 namespace {
+bool same_batch(const bt_batch &a, const bt_batch &b) {
+    return a.batch == b.batch && a.stm == b.stm && a.nstm == b.nstm && a.buckets == b.buckets && a.targets == b.targets &&
+           a.entry_weights == b.entry_weights;
+}
+
+// A steady-state step as one hipGraph launch (bt_net_use_graphs). Eligible: this batch's index was built ahead, the next
+// batch is hinted, a stream of the caller's (capture needs one), and the step takes the single-layer fused path -- which
+// the first attempt finds out by capturing the ordinary enqueue code (cap_ok). Anything else, and any failure while
+// capturing, runs the step the ordinary way; a failure switches graphs off for this net.
+// Events: the two that come from outside (the hinted batch's ready event, the side stream's build left by an eager step)
+// are joined on the stream before the launch, the caller's completion event is recorded behind it; inside the graph the
+// side stream's work for the next batch is a branch (fork / join by events of the net, i.e. edges).
+int forward_backward_eager(bt_net *n, void *stream, const bt_batch *b, float *loss_sum_dev, StepOpt *opt);
 int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *loss_sum_dev, StepOpt *opt) {
+    const bool ready = n->prepared && same_batch(n->prep_key, *b) && n->ft_ws_alt;
+    const bool eligible = n->use_graphs && stream && ready && n->has_next && loss_sum_dev && (!opt || (opt->adj && opt->lr)) &&
+                          !bt_capturing() && !bt_prof_active();  // (a graph's kernels carry no per-kernel timestamps)
+    if (!eligible) {
+        n->last_graph = false;
+        return forward_backward_eager(n, stream, b, loss_sum_dev, opt);
+    }
+    if (int rc = check_batch(n, b, "bt_net_forward_backward")) return rc;
+    hipStream_t s = bt_stream(stream);
+    // (the graph of this step uses the buffer set that is about to be swapped in: ft_ws_alt)
+    bt_net::StepGraph *g = nullptr;
+    for (auto &e : n->graphs)
+        if (same_batch(e.cur, *b) && same_batch(e.next, n->next) && e.loss == loss_sum_dev && e.ws == n->ft_ws_alt &&
+            e.stream == s && e.with_opt == (opt != nullptr) && (!opt || (e.adj == opt->adj && e.lr == opt->lr)))
+            g = &e;
+    // joins with what lies outside the graph
+    if (!n->last_graph) BT_HIP(hipStreamWaitEvent(s, n->ev_next, 0));
+    if (n->next_ready && hipEventQuery(n->next_ready) != hipSuccess) {
+        (void)hipGetLastError();
+        BT_HIP(hipStreamWaitEvent(s, n->next_ready, 0));
+    }
+    hipEvent_t done = opt ? opt->done : nullptr;
+    if (!g) {
+        if (n->graphs.size() >= 16) {  // (a caller that rotates through more buffers than that: not worth graphs)
+            n->use_graphs = false, n->last_graph = false;
+            return forward_backward_eager(n, stream, b, loss_sum_dev, opt);
+        }
+        bt_net::StepGraph e{*b, n->next, loss_sum_dev, opt ? opt->adj : nullptr, opt ? opt->lr : nullptr, n->ft_ws_alt, s,
+                            opt != nullptr, false, nullptr};
+        n->capturing = true, n->cap_ok = false;
+        bt_set_capturing(true);
+        hipGraph_t graph = nullptr;
+        int rc = BT_OK;
+        hipError_t he = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+        if (he == hipSuccess) {
+            StepOpt o2 = opt ? *opt : StepOpt{nullptr, nullptr, nullptr};
+            rc = forward_backward_eager(n, stream, b, loss_sum_dev, opt ? &o2 : nullptr);
+            e.stepped = o2.stepped;
+            if (opt && !o2.stepped) n->cap_ok = false;  // (an optimiser step of its own keeps host-side counters: not captured)
+            // the side stream's branch back into the compute stream
+            if (hipEventRecord(n->ev_cap_join, n->side) != hipSuccess || hipStreamWaitEvent(s, n->ev_cap_join, 0) != hipSuccess)
+                rc = rc ? rc : BT_ERR_HIP;
+            he = hipStreamEndCapture(s, &graph);
+        }
+        bt_set_capturing(false);
+        n->capturing = false;
+        const bool ok = he == hipSuccess && rc == BT_OK && n->cap_ok && graph &&
+                        hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        if (!ok) {
+            // The capture ran the step's host-side bookkeeping (buffer sets swapped, the next batch marked as prepared) but
+            // enqueued nothing: undo the bookkeeping and run this step, and every later one, the ordinary way.
+            bt_set_error("bt_net: the step could not be captured into a graph; running without graphs");
+            std::swap(n->ft_ws, n->ft_ws_alt), std::swap(n->perm, n->perm_alt);
+            n->prepared = true, n->prep_key = *b, n->has_next = true, n->next = e.next;
+            n->prev_done = nullptr, n->use_graphs = false, n->last_graph = false;
+            BT_HIP(hipStreamSynchronize(s));  // (what the side stream built for this batch has been joined above)
+            BT_HIP(hipStreamSynchronize(n->side));
+            return forward_backward_eager(n, stream, b, loss_sum_dev, opt);
+        }
+        n->graphs.push_back(e);
+        g = &n->graphs.back();
+    } else {
+        // the bookkeeping the ordinary path does for such a step
+        std::swap(n->ft_ws, n->ft_ws_alt), std::swap(n->perm, n->perm_alt);
+        n->prepared = true, n->prep_key = n->next, n->has_next = false;
+    }
+    n->prev_done = nullptr;
+    BT_HIP(hipGraphLaunch(g->exec, s));
+    if (opt) opt->stepped = g->stepped;
+    if (done) BT_HIP(hipEventRecord(done, s));
+    n->last_graph = true, n->graph_launches++;
+    return BT_OK;
+}
+
+int forward_backward_eager(bt_net *n, void *stream, const bt_batch *b, float *loss_sum_dev, StepOpt *opt) {
     if (int rc = check_batch(n, b, "bt_net_forward_backward")) return rc;
     BT_REQUIRE(loss_sum_dev, "bt_net_forward_backward: null loss buffer");
     hipStream_t s = bt_stream(stream);
@@ -578,7 +692,8 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
         // whole build ended during the previous step anyway).
         if (bt_internal_ft_grouped(&f)) BT_HIP(hipStreamWaitEvent(s, n->ev_next_groups, 0));
         else {
-            BT_HIP(hipStreamWaitEvent(s, n->ev_next, 0));
+            // (under capture the join is made before the graph is launched, graph_step)
+            if (!n->capturing) BT_HIP(hipStreamWaitEvent(s, n->ev_next, 0));
             joined = true;
         }
     } else {
@@ -627,9 +742,15 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
     // The side stream's work for the NEXT batch (prepare_next) has to stay behind the last readers of the second buffer
     // set, the step before this one. Single-layer fused path: behind that step's completion event, which rode on its
     // merge kernel -- no packet on `s` at all. Otherwise behind a fork event recorded on `s` here.
-    const bool fork_by_done = ready && head_grads_in_ft && prev_done;
-    if (fork_by_done) BT_HIP(hipStreamWaitEvent(n->side, prev_done, 0));
-    else if (ready && !tail) BT_HIP(hipEventRecord(n->ev_fork, s));
+    const bool fork_by_done = ready && head_grads_in_ft && (prev_done || n->capturing);
+    if (n->capturing) {  // inside a graph the fork is an edge, not a packet: the side stream joins the capture
+        BT_HIP(hipEventRecord(n->ev_fork, s));
+        BT_HIP(hipStreamWaitEvent(n->side, n->ev_fork, 0));
+    } else if (fork_by_done) {
+        BT_HIP(hipStreamWaitEvent(n->side, prev_done, 0));
+    } else if (ready && !tail) {
+        BT_HIP(hipEventRecord(n->ev_fork, s));
+    }
     if (int rc = forward_impl(n, s, b, fuse_loss && !tail, side_head, head_in_ft, true, perm.built && !ready,
                               tail ? 1 : -1, !head_grads_in_ft, ready && !joined ? n->ev_next : nullptr, joined))
         return rc;
@@ -692,6 +813,7 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
             return rc;
         if (int rc = factor_reduce()) return rc;
         if (hinted && n->d.ft_factoriser <= 0) n->prev_done = hg.done;  // (the merge is this step's last kernel)
+        if (n->capturing) n->cap_ok = ready && hinted && fork_by_done && n->d.ft_factoriser <= 0;
         return prepare_next(n, fork_by_done);
     }
     if (side_head) {
@@ -785,6 +907,14 @@ int forward_backward_impl(bt_net *n, void *stream, const bt_batch *b, float *los
     return prepare_next(n, ready && tail);
 }
 }  // namespace
+
+int bt_net_use_graphs(bt_net *n, int on) {
+    BT_REQUIRE(n, "bt_net_use_graphs: null net");
+    n->use_graphs = on != 0;
+    if (!on) bt_internal_net_drop_graphs(n);
+    return BT_OK;
+}
+int bt_net_graph_launches(const bt_net *n) { return n ? n->graph_launches : 0; }
 
 int bt_net_hint_next_batch(bt_net *n, const bt_batch *next, void *ready_event) {
     BT_REQUIRE(n, "bt_net_hint_next_batch: null net");
@@ -960,6 +1090,7 @@ int bt_net_set_optimiser(bt_net *n, int kind, float n_sma_threshold, float alpha
     BT_REQUIRE(n, "bt_net_set_optimiser: null net");
     BT_REQUIRE(kind >= BT_OPT_ADAMW && kind <= BT_OPT_RANGER, "bt_net_set_optimiser: unknown optimiser %d", kind);
     BT_REQUIRE(kind != BT_OPT_RANGER || k >= 1, "bt_net_set_optimiser: k must be >= 1");
+    bt_internal_net_drop_graphs(n);
     n->opt_kind = kind, n->opt_step = 0, n->opt_thr = n_sma_threshold, n->opt_alpha = alpha, n->opt_k = k > 0 ? k : 6;
     BT_HIP(hipMemset(n->mom, 0, n->n_params * sizeof(float)));  // OptimiserState::reset
     BT_HIP(hipMemset(n->vel, 0, n->n_params * sizeof(float)));

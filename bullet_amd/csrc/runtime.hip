@@ -64,6 +64,8 @@ int bt_prof_register(const char *kernel_expr) {
     return (int)names.size() - 1;
 }
 
+bool bt_prof_active() { return g_prof.on; }
+
 bool bt_prof_enabled(int id) {
     Profiler &p = g_prof;
     if (!p.on) return false;
@@ -108,6 +110,11 @@ namespace {
 thread_local int tl_stop_kernel = -1;
 thread_local hipEvent_t tl_stop_event = nullptr;
 }  // namespace
+namespace {
+thread_local bool tl_capturing = false;
+}
+bool bt_capturing() { return tl_capturing; }
+void bt_set_capturing(bool on) { tl_capturing = on; }
 void bt_attach_stop_event(int kernel_id, hipEvent_t ev) { tl_stop_kernel = kernel_id, tl_stop_event = ev; }
 hipEvent_t bt_take_stop_event(int kernel_id) {
     if (kernel_id != tl_stop_kernel || !tl_stop_event) return nullptr;

@@ -160,7 +160,7 @@ SYMBOLS = [
     "bt_net_param_count", "bt_net_num_tensors", "bt_net_tensor_size", "bt_net_tensor_offset", "bt_net_create",
     "bt_net_destroy", "bt_net_params", "bt_net_grads", "bt_net_momentum", "bt_net_velocity", "bt_net_set_adamw",
     "bt_net_flat_size", "bt_net_max_batch", "bt_net_grads_owned", "bt_chessboard_from_str", "bt_measure_loader_throughput", "bt_reader_open_viribinpack", "bt_reader_open_sfbinpack",
-    "bt_reader_open_viribinpack_builtin", "bt_viri_filter_default", "bt_viri_filter_unrestricted", "bt_reader_open_montybinpack",
+    "bt_reader_open_viribinpack_builtin", "bt_viri_filter_default", "bt_viri_filter_unrestricted", "bt_reader_open_montybinpack", "bt_net_use_graphs", "bt_net_graph_launches",
     "bt_net_forward_backward", "bt_net_optimiser_step", "bt_net_optimiser_step_event", "bt_net_train_step", "bt_net_forward", "bt_net_hint_next_batch",
     "bt_input_init", "bt_input_num_inputs", "bt_input_max_active", "bt_map_batch", "bt_map_batch_device", "bt_map_batch_device_errors",
     "bt_net_init_weights_host", "bt_lr_at", "bt_wdl_at", "bt_reader_open", "bt_reader_next", "bt_reader_close",

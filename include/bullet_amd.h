@@ -336,12 +336,23 @@ int bt_net_forward_backward(bt_net *net, void *stream, const bt_batch *batch, fl
  * (same net, its tensors complete in `stream` order by now, or once `ready_event` -- a hipEvent_t, may be NULL -- has
  * fired). Multi-layer / king-bucketed nets then build next's index structures (entry lists, bucket order, sorted
  * lists: they depend on the indices only) on their side stream while the current step runs, in a second buffer
- * set, and the following bt_net_forward_backward(next) starts with them in place. The single-layer bucketed net keeps
- * building the index beside its forward pass, but puts its side stream behind the current step and `ready_event` when
- * the current step ends, so the following step forks without an event packet on `stream` (~5 us). Results are
+ * set, and the following bt_net_forward_backward(next) starts with them in place. The single-layer bucketed net does
+ * the same (its forward lists are decoded there too) and orders the side stream behind the completion event that rode
+ * on the previous step's last kernel, so no step records a fork event on `stream` (~5 us each). Results are
  * identical with or without the hint; a hint that does not match the following call is ignored. No counterpart in the
  * reference. */
 int bt_net_hint_next_batch(bt_net *net, const bt_batch *next, void *ready_event);
+/* Steady-state steps as one hipGraph launch each (no counterpart in the reference). With `on`, a
+ * bt_net_train_step / bt_net_forward_backward whose batch was announced by bt_net_hint_next_batch during the step
+ * before, and which itself has a next batch announced, is captured the first time its combination of batch tensors,
+ * next-batch tensors, buffers and stream is seen (single-layer fused nets on a caller's stream; anything else, and any
+ * capture failure, runs the ordinary way) and replayed afterwards: one driver call instead of about ten. Off by default,
+ * and measured slower on ROCm 7.2 -- one hipGraphLaunch of this graph costs the host more than the ten calls it
+ * replaces; kept for stacks where that changes. Results are bit-identical. The batch's ready event and `done_event` keep
+ * their meaning. While the calling thread's profiler is armed (bt_profile_start) steps run the ordinary way: kernels
+ * inside a graph carry no timestamps. bt_net_graph_launches: how many steps have run as graphs. */
+int bt_net_use_graphs(bt_net *net, int on);
+int bt_net_graph_launches(const bt_net *net);
 /* AdamW on every tensor with g = adj * grad (adj = 1/global_batch), adam.rs:121-131 */
 int bt_net_optimiser_step(bt_net *net, void *stream, const float *adj_dev, const float *lr_dev);
 /* the same, and `done_event` (a hipEvent_t, may be NULL) fires when the update is complete. It travels on the update

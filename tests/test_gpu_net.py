@@ -401,6 +401,70 @@ def test_hinted_train_steps_queued_without_host_syncs(name):
         assert loss == runs[0][0] and torch.equal(params, runs[0][1])
 
 
+@pytest.mark.parametrize("with_opt", [True, False])
+def test_graph_steps_change_nothing(with_opt):
+    """bt_net_use_graphs: steady-state steps of the single-layer fused net replayed as hipGraphs (three rotating
+    batches, next batch hinted, a stream of the library's) leave the bits of the same steps run the ordinary way --
+    losses of every step, parameters and optimiser state -- for bt_net_train_step and for bt_net_forward_backward +
+    bt_net_optimiser_step (the data-parallel shape of a step); a change of the optimiser settings in mid-run drops the
+    captured graphs; a net whose step takes another path keeps running without graphs."""
+    cfg, (kind, layout, fact), nb, ft_eff = NETS["cfg2_buckets"]
+    batches = fixture_batches(kind, layout, fact, nb, 0.75, 3, batch=2048)
+    dev_b = [[gu.dev(a) for a in bt] for bt in batches]
+    sh = C.c_void_p()
+    lib.check(L.bt_stream_create(C.byref(sh)))
+    runs = []
+    for graphs in (False, True):
+        net = lib.Net(lib.make_net_desc(**cfg), 2048)
+        net.init_weights(seed=5, ft_effective_inputs=ft_eff)
+        lib.check(L.bt_net_use_graphs(net.h, int(graphs)))
+        tbs = [net.make_batch(*t) for t in dev_b]
+        adj, lrd = torch.tensor([1.0 / 2048], device="cuda"), torch.tensor([0.001], device="cuda")
+        losses = torch.zeros(20, device="cuda")
+        torch.cuda.synchronize()
+        for i in range(20):
+            if i == 14:
+                lib.check(L.bt_net_set_adamw(net.h, 0, 0.02, 0.9, 0.999, -1.5, 1.5))
+            net.hint_next(tbs[(i + 1) % 3])
+            if with_opt:
+                lib.check(L.bt_net_train_step(net.h, sh.value, C.byref(tbs[i % 3]), losses[i:].data_ptr(), adj.data_ptr(),
+                                              lrd.data_ptr(), None))
+            else:
+                lib.check(L.bt_net_forward_backward(net.h, sh.value, C.byref(tbs[i % 3]), losses[i:].data_ptr()))
+                lib.check(L.bt_net_optimiser_step(net.h, sh.value, adj.data_ptr(), lrd.data_ptr()))
+        lib.check(L.bt_stream_sync(sh))
+        n_graph = L.bt_net_graph_launches(net.h)
+        assert (n_graph >= 12) if graphs else (n_graph == 0), n_graph
+        runs.append((losses.cpu().tolist(), net.params.clone(), net.state_view("momentum")))
+        net.close()
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
+    for a, b in zip(runs[0][2], runs[1][2]):
+        assert np.array_equal(a, b)
+    # a multi-layer net: not the captured path -- the first attempt finds out and the run goes on without graphs
+    cfg, (kind, layout, fact), nb, ft_eff = NETS["cfg3_multilayer_segment"]
+    batches = fixture_batches(kind, layout, fact, nb, 0.75, 3, batch=1024)
+    dev_b = [[gu.dev(a) for a in bt] for bt in batches]
+    runs = []
+    for graphs in (False, True):
+        net = lib.Net(lib.make_net_desc(**cfg), 1024)
+        net.init_weights(seed=5, ft_effective_inputs=ft_eff)
+        lib.check(L.bt_net_use_graphs(net.h, int(graphs)))
+        tbs = [net.make_batch(*t) for t in dev_b]
+        adj, lrd = torch.tensor([1.0 / 1024], device="cuda"), torch.tensor([0.001], device="cuda")
+        losses = torch.zeros(8, device="cuda")
+        torch.cuda.synchronize()
+        for i in range(8):
+            net.hint_next(tbs[(i + 1) % 3])
+            lib.check(L.bt_net_train_step(net.h, sh.value, C.byref(tbs[i % 3]), losses[i:].data_ptr(), adj.data_ptr(),
+                                          lrd.data_ptr(), None))
+        lib.check(L.bt_stream_sync(sh))
+        assert L.bt_net_graph_launches(net.h) == 0
+        runs.append((losses.cpu().tolist(), net.params.clone()))
+        net.close()
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
+    L.bt_stream_destroy(sh)
+
+
 @pytest.mark.parametrize("hidden", [1024, 1536])
 def test_full_size_config3_config4_properties(hidden):
     """BASELINE configs[2] (H = 1024) and configs[3] (H = 1536: the per-GPU net of the data-parallel config,
