@@ -197,6 +197,23 @@ pub mod ffi {
         unsafe extern "C" fn(user: *mut c_void, chessboard32: *const c_void, mv: u16, eval: i16, wdl: f32, ply: c_int) -> c_int,
     >;
     pub type bt_sf_filter = Option<unsafe extern "C" fn(user: *mut c_void, entry: *const bt_sf_entry) -> c_int>;
+    pub type bt_monty_filter =
+        Option<unsafe extern "C" fn(user: *mut c_void, chessboard32: *const c_void, mv: u16, score: i16, result: f32) -> c_int>;
+
+    /// `viriformat::dataformat::Filter` as the library restates it (`ViriFilter::Builtin`)
+    #[repr(C)]
+    #[derive(Clone, Copy, Debug)]
+    pub struct bt_viri_builtin_filter {
+        pub min_ply: u32,
+        pub min_pieces: u32,
+        pub max_eval: u32,
+        pub filter_tactical: c_int,
+        pub filter_check: c_int,
+        pub filter_castling: c_int,
+        pub max_eval_incorrectness: u32,
+        pub random_fen_skipping: c_int,
+        pub random_fen_skip_probability: f64,
+    }
 
     extern "C" {
         pub fn bt_last_error() -> *const c_char;
@@ -253,6 +270,9 @@ pub mod ffi {
         pub fn bt_comm_init_rank(id128: *const c_void, rank: c_int, world: c_int, comm: *mut *mut c_void) -> c_int;
         pub fn bt_comm_from_hooks(hooks: *const bt_comm_hooks, rank: c_int, world: c_int, comm: *mut *mut c_void) -> c_int;
         pub fn bt_comm_destroy(comm: *mut c_void) -> c_int;
+        pub fn bt_comm_available() -> c_int;
+        pub fn bt_comm_use_own_stream(comm: *mut c_void) -> c_int;
+        pub fn bt_net_use_graphs(net: *mut bt_net, on: c_int) -> c_int;
         pub fn bt_allreduce_sum_f32(comm: *mut c_void, stream: *mut c_void, buf_dev: *mut f32, n: usize) -> c_int;
         pub fn bt_net_dp_plan(desc: *const bt_net_desc, world: c_int, rank: c_int, shard_min_floats: usize, plan: *mut bt_dp_plan) -> c_int;
         pub fn bt_net_dp_step(
@@ -276,6 +296,16 @@ pub mod ffi {
         ) -> c_int;
         pub fn bt_reader_open_sfbinpack(
             paths: *const *const c_char, n_paths: c_int, buffer_size_mb: usize, threads: c_int, filter: bt_sf_filter,
+            user: *mut c_void, shuffle_seed: u64, reader: *mut *mut bt_reader,
+        ) -> c_int;
+        pub fn bt_viri_filter_default(filter: *mut bt_viri_builtin_filter);
+        pub fn bt_viri_filter_unrestricted(filter: *mut bt_viri_builtin_filter);
+        pub fn bt_reader_open_viribinpack_builtin(
+            paths: *const *const c_char, n_paths: c_int, buffer_size_mb: usize, threads: c_int,
+            filter: *const bt_viri_builtin_filter, shuffle_seed: u64, reader: *mut *mut bt_reader,
+        ) -> c_int;
+        pub fn bt_reader_open_montybinpack(
+            paths: *const *const c_char, n_paths: c_int, buffer_size_mb: usize, threads: c_int, filter: bt_monty_filter,
             user: *mut c_void, shuffle_seed: u64, reader: *mut *mut bt_reader,
         ) -> c_int;
         pub fn bt_reader_next(reader: *mut bt_reader, dst_records: *mut c_void, count: c_int) -> c_int;
@@ -396,6 +426,37 @@ impl Reader {
         let mut raw = std::ptr::null_mut();
         check(unsafe {
             ffi::bt_reader_open_viribinpack(p.as_ptr(), p.len() as c_int, buffer_size_mb, threads as c_int, None, std::ptr::null_mut(), 0, &mut raw)
+        })?;
+        Ok(Self { raw })
+    }
+
+    /// `ViriBinpackLoader::new(path, mb, threads, Filter::default())`: the crate's built-in filter with its defaults
+    pub fn viribinpack_builtin(paths: &[&str], buffer_size_mb: usize, threads: usize, filter: Option<ffi::bt_viri_builtin_filter>) -> Result<Self, Error> {
+        let c: Vec<CString> = paths.iter().map(|p| CString::new(*p).unwrap()).collect();
+        let p: Vec<*const c_char> = c.iter().map(|s| s.as_ptr()).collect();
+        let f = filter.unwrap_or_else(|| {
+            let mut f = std::mem::MaybeUninit::<ffi::bt_viri_builtin_filter>::zeroed();
+            unsafe {
+                ffi::bt_viri_filter_default(f.as_mut_ptr());
+                f.assume_init()
+            }
+        });
+        let mut raw = std::ptr::null_mut();
+        check(unsafe {
+            ffi::bt_reader_open_viribinpack_builtin(p.as_ptr(), p.len() as c_int, buffer_size_mb, threads as c_int, &f, 0, &mut raw)
+        })?;
+        Ok(Self { raw })
+    }
+
+    /// `MontyBinpackLoader::new(path, mb, threads, filter)`
+    pub fn montybinpack(
+        paths: &[&str], buffer_size_mb: usize, threads: usize, filter: ffi::bt_monty_filter, user: *mut c_void,
+    ) -> Result<Self, Error> {
+        let c: Vec<CString> = paths.iter().map(|p| CString::new(*p).unwrap()).collect();
+        let p: Vec<*const c_char> = c.iter().map(|s| s.as_ptr()).collect();
+        let mut raw = std::ptr::null_mut();
+        check(unsafe {
+            ffi::bt_reader_open_montybinpack(p.as_ptr(), p.len() as c_int, buffer_size_mb, threads as c_int, filter, user, 0, &mut raw)
         })?;
         Ok(Self { raw })
     }
