@@ -32,9 +32,10 @@ __host__ __device__ inline int ft_sorted_cap(int nnz, int cols) { return (FT_CHU
 // Test switches, read from the environment when the library is loaded and again only when a test asks for it
 // (bt_internal_reload_env): BT_FT_FORCE_GENERIC=1 runs the any-shape kernels on every shape, BT_FT_FORCE_GROUPED=1
 // the segment-grouped ones wherever a segment is given, BT_FT_FWD_ITEM / BT_FT_BWD_CHUNKS override the item sizes,
-// BT_FT_NO_PREDEC=1 makes the fused-head forward decode its lists itself (as the op-level forward does).
+// BT_FT_NO_PREDEC=1 makes the fused-head forward decode its lists itself (as the op-level forward does),
+// BT_FT_DECODE_PARITY=0 keeps the decoded lists in list order.
 struct FtEnv {
-    bool force_generic = false, force_grouped = false, no_predec = false;
+    bool force_generic = false, force_grouped = false, no_predec = false, decode_parity = true;
     int fwd_item = 0, bwd_chunks = 0;
     FtEnv() { reload(); }
     void reload() {
@@ -45,6 +46,7 @@ struct FtEnv {
         force_generic = num("BT_FT_FORCE_GENERIC") == 1, force_grouped = num("BT_FT_FORCE_GROUPED") != 0;
         fwd_item = num("BT_FT_FWD_ITEM"), bwd_chunks = num("BT_FT_BWD_CHUNKS");
         no_predec = num("BT_FT_NO_PREDEC") == 1;
+        decode_parity = !(getenv("BT_FT_DECODE_PARITY") && getenv("BT_FT_DECODE_PARITY")[0] == '0');
     }
 };
 FtEnv g_ft_env;
@@ -867,7 +869,8 @@ __device__ __forceinline__ void add4(float4 &a, const float4 &v) { a.x += v.x, a
 // at a time. The wave's index lists are validated once (stop rule, write.rs:231), turned into byte offsets of
 // tile rows (masked slots -> the zero row) and parked in a per-wave LDS strip; the gather loop then costs, per 4
 // features, 1 ds_read_b128 of offsets + 4 address adds + 4 ds_read_b128 gathers + 8 packed adds: 0.75 VALU per
-// summed element. The sum runs over the features in list order, like the reference's loop (sparse.rs:100-113).
+// summed element. The sum runs over the features in list order, like the reference's loop (sparse.rs:100-113) -- or, with
+// lists decoded ahead (PRE), in the order ft_fwd_decode_kernel<PARITY> gave them: the same rows, sorted by parity.
 constexpr int FWD_EPW = 8;  // entries per wave per pass
 
 // ds_read_b128 is served in four 16-lane groups, {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32; only
@@ -918,6 +921,12 @@ __device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lanes of
 // decode map of ft_fwd_lds. offs[e][32]: byte offset of the tile row of every slot, masked slots (behind the first
 // invalid index, write.rs:231) -> the zero row `cols`; nblk[e / 8]: the 4-slot blocks that hold a live slot for at
 // least one of the group's eight entries (live blocks form a prefix in every entry).
+// PARITY: an entry's live rows are listed by the parity of the row number -- even rows first for even entries, odd rows
+// first for odd ones, each kind in list order, the masked slots behind them. One 16-lane service group of the forward's
+// gathers reads a whole 128-B row for each of two neighbouring entries (fwd_gather_slot), and two rows of equal parity
+// collide in the LDS banks: a coin flip in list order, rare in this order. The sum of an entry then runs over the same
+// rows in another (still fixed) order.
+template <bool PARITY>
 __global__ __launch_bounds__(256) void ft_fwd_decode_kernel(const int32_t *__restrict__ idx0,
                                                             const int32_t *__restrict__ idx1, int batch, int nnz, int cols,
                                                             int E, lds_u4_t *__restrict__ offs, uint8_t *__restrict__ nblk) {
@@ -937,12 +946,47 @@ __global__ __launch_bounds__(256) void ft_fwd_decode_kernel(const int32_t *__res
     const unsigned m = (unsigned)(__ballot(any) >> (eslot * 8)) & 0xFFu;
     bool kill = e >= E || (m & ((1u << sub) - 1u));
     const unsigned long long open = __ballot(!(kill || inv[0]));
-    lds_u4_t o;
-    kill |= inv[0], o.x = (unsigned)(kill ? cols : r[0]) * (LDS_RT * 4);
-    kill |= inv[1], o.y = (unsigned)(kill ? cols : r[1]) * (LDS_RT * 4);
-    kill |= inv[2], o.z = (unsigned)(kill ? cols : r[2]) * (LDS_RT * 4);
-    kill |= inv[3], o.w = (unsigned)(kill ? cols : r[3]) * (LDS_RT * 4);
-    if (e < E) offs[(size_t)e * 8 + sub] = o;
+    if constexpr (PARITY) {
+        // positions: packed (even | odd << 16) counts of live rows, scanned over the entry's 8 lanes by DPP row shifts
+        unsigned r4[4];
+        bool lv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            kill |= inv[j];
+            lv[j] = !kill;
+            r4[j] = (unsigned)(kill ? cols : r[j]);
+        }
+        unsigned c = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) c += lv[j] ? ((r4[j] & 1u) ? 0x10000u : 1u) : 0u;
+        int sc = (int)c;
+        sc += __builtin_amdgcn_update_dpp(0, sc, 0x111, 0xF, 0xF, true);  // row_shr:1 ... 8: inclusive scan of a 16-lane row
+        sc += __builtin_amdgcn_update_dpp(0, sc, 0x112, 0xF, 0xF, true);
+        sc += __builtin_amdgcn_update_dpp(0, sc, 0x114, 0xF, 0xF, true);
+        sc += __builtin_amdgcn_update_dpp(0, sc, 0x118, 0xF, 0xF, true);
+        const unsigned t7 = (unsigned)row_share<7>(sc), t15 = (unsigned)row_share<15>(sc);
+        const bool hi8 = (lane & 8) != 0;  // the row's second entry
+        const unsigned tot = hi8 ? t15 - t7 : t7;
+        const unsigned before = (hi8 ? (unsigned)sc - t7 : (unsigned)sc) - c;
+        const bool odd_first = (e & 1) != 0;
+        unsigned pos_e = (odd_first ? tot >> 16 : 0u) + (before & 0xffffu);
+        unsigned pos_o = (odd_first ? 0u : tot & 0xffffu) + (before >> 16);
+        unsigned *mine = reinterpret_cast<unsigned *>(offs + (size_t)min(e, E - 1) * 8);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool od = (r4[j] & 1u) != 0;
+            const unsigned at = lv[j] ? (od ? pos_o : pos_e) : (unsigned)(sub * 4 + j);
+            pos_o += (lv[j] && od) ? 1u : 0u, pos_e += (lv[j] && !od) ? 1u : 0u;
+            if (e < E) mine[at] = r4[j] * (LDS_RT * 4);
+        }
+    } else {
+        lds_u4_t o;
+        kill |= inv[0], o.x = (unsigned)(kill ? cols : r[0]) * (LDS_RT * 4);
+        kill |= inv[1], o.y = (unsigned)(kill ? cols : r[1]) * (LDS_RT * 4);
+        kill |= inv[2], o.z = (unsigned)(kill ? cols : r[2]) * (LDS_RT * 4);
+        kill |= inv[3], o.w = (unsigned)(kill ? cols : r[3]) * (LDS_RT * 4);
+        if (e < E) offs[(size_t)e * 8 + sub] = o;
+    }
     unsigned fold = (unsigned)open | (unsigned)(open >> 32);
     fold |= fold >> 16;
     fold |= fold >> 8;
@@ -951,7 +995,7 @@ __global__ __launch_bounds__(256) void ft_fwd_decode_kernel(const int32_t *__res
 
 // PRE: the lists were validated and decoded once per batch (ft_fwd_decode_kernel) instead of once per row tile here:
 // pre.offs holds each entry's 32 strip words as the decode below would form them, pre.nblk the live 4-slot blocks of
-// every aligned group of 8 entries. Same rows in the same order, so the same bits.
+// every aligned group of 8 entries. The same rows (in list order without PARITY: then the same bits).
 struct FtPre {
     const lds_u4_t *offs;  // [E][8]
     const uint8_t *nblk;   // [ceil(E / 8)]
@@ -2359,9 +2403,14 @@ int bt_internal_ft_build_groups(void *stream, const bt_ft_desc *d, const int32_t
     const int E = d->n_inputs * d->batch;
     if (p.predec) {
         if (done) bt_attach_stop_event(BTK_FT_INDEX, done);
-        BT_LAUNCH(BTK_FT_INDEX, s, ft_fwd_decode_kernel, dim3(bt_div_up((long long)E * 8, 256)), dim3(256), 0, i0, i1, d->batch,
-                  d->nnz, d->cols, E, reinterpret_cast<lds_u4_t *>(ws + p.off_foffs),
-                  reinterpret_cast<uint8_t *>(ws + p.off_fblk));
+        if (g_ft_env.decode_parity)
+            BT_LAUNCH(BTK_FT_INDEX, s, ft_fwd_decode_kernel<true>, dim3(bt_div_up((long long)E * 8, 256)), dim3(256), 0, i0, i1,
+                      d->batch, d->nnz, d->cols, E, reinterpret_cast<lds_u4_t *>(ws + p.off_foffs),
+                      reinterpret_cast<uint8_t *>(ws + p.off_fblk));
+        else
+            BT_LAUNCH(BTK_FT_INDEX, s, ft_fwd_decode_kernel<false>, dim3(bt_div_up((long long)E * 8, 256)), dim3(256), 0, i0, i1,
+                      d->batch, d->nnz, d->cols, E, reinterpret_cast<lds_u4_t *>(ws + p.off_foffs),
+                      reinterpret_cast<uint8_t *>(ws + p.off_fblk));
         BT_LAUNCH_CHECK();
         return BT_OK;
     }
