@@ -2107,6 +2107,9 @@ int ft_plan(const bt_ft_desc *d, FtPlan *p) {
     p->hdw = p->oct && !p->grouped && !d->pairwise && p->chunks_per_input % p->chunks_per_wg == 0 &&
              (size_t)p->tc * LDS_RT >= (size_t)(LDS_THREADS / 64) * FtPlan::kFusedMaxRows * 64;
     if (p->hdw) p->off_pw1 = o, o += bt_align((size_t)p->G * p->pw1_stride * sizeof(float));
+    // (not for segment-grouped tables: tried, by list position, with and without the parity order -- cfg3 0.449 -> 0.446 ms,
+    // all of it from the parity order, which makes the grouped forward differ from the ungrouped one in bits and moves a
+    // few dozen CReLU boundary cases of 19 M gradient elements past the bar between the two paths: not kept)
     p->predec = p->lds_path && !p->grouped && d->nnz <= 32 && !g_ft_env.no_predec;
     p->off_foffs = p->off_fblk = 0;
     if (p->predec) {
