@@ -114,6 +114,8 @@ hipEvent_t bt_take_stop_event(int kernel_id);
 bool bt_prof_take_pair(int id, hipEvent_t *a, hipEvent_t *b);
 // While the calling thread captures a step into a hipGraph (net.hip), launches are plain: no timing, and a completion
 // event that would ride on the packet is dropped (the capturing code records it after the graph's launch instead).
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel) and size reached so far, not once per launch
+int bt_set_max_lds(const void *kernel, size_t bytes);
 bool bt_capturing();
 void bt_set_capturing(bool on);
 #define BT_LAUNCH(id, stream, kernel, grid, block, lds, ...)                                        \

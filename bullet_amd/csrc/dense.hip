@@ -1447,9 +1447,7 @@ bool dense_bwd_small_ok(const bt_dense_desc *d) { return d->out == 1 && d->bucke
 
 template <typename K>
 int dense_set_lds(K kernel, size_t bytes) {
-    BT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)bytes));
-    return BT_OK;
+    return bt_set_max_lds(reinterpret_cast<const void *>(kernel), bytes);
 }
 
 int dense_fwd_small_launch(hipStream_t s, const bt_dense_desc *d, const float *w, const float *bias, const float *x,

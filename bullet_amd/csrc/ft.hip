@@ -2122,9 +2122,7 @@ int ft_plan(const bt_ft_desc *d, FtPlan *p) {
 
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
-    BT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)bytes));
-    return BT_OK;
+    return bt_set_max_lds(reinterpret_cast<const void *>(kernel), bytes);
 }
 
 // the group tables inside a workspace; `fwd` selects which item list the kernels walk

@@ -3,7 +3,9 @@
 // ROCm implementation crates/gpu/src/runtime/rocm.rs:66-171), straight on the HIP runtime.
 #include <cstring>
 #include <string>
+#include <map>
 #include <mutex>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -110,6 +112,21 @@ namespace {
 thread_local int tl_stop_kernel = -1;
 thread_local hipEvent_t tl_stop_event = nullptr;
 }  // namespace
+int bt_set_max_lds(const void *kernel, size_t bytes) {
+    // (the attribute belongs to the kernel on the current device; a launch is a few microseconds of host time, and so is
+    // this call: it is made when a kernel first needs more dynamic LDS than it has been granted on this device)
+    static std::mutex m;
+    static std::map<std::pair<int, const void *>, size_t> granted;
+    int dev = 0;
+    BT_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(m);
+    size_t &g = granted[{dev, kernel}];
+    if (bytes <= g) return BT_OK;
+    BT_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    g = bytes;
+    return BT_OK;
+}
+
 namespace {
 thread_local bool tl_capturing = false;
 }
