@@ -993,6 +993,11 @@ __global__ __launch_bounds__(256) void ft_fwd_decode_kernel(const int32_t *__res
     if (lane == 0 && e < E) nblk[e >> 3] = (uint8_t)__popc(fold & 0xFFu);
 }
 
+// (Tried: the entries put in an order in which the 128 entries of a workgroup's pass have equal list lengths -- a pass
+// walks as many 4-slot blocks as its longest list -- by a counting sort on the side stream. At the fixture's piece counts
+// the forward went from 70 to 62.5 us, at full occupancy from 69.5 to 72.5 (the indirection, scattered partial writes),
+// and the sort needs more than one workgroup to stay off the critical path: not kept.)
+
 // PRE: the lists were validated and decoded once per batch (ft_fwd_decode_kernel) instead of once per row tile here:
 // pre.offs holds each entry's 32 strip words as the decode below would form them, pre.nblk the live 4-slot blocks of
 // every aligned group of 8 entries. The same rows (in list order without PARITY: then the same bits).
@@ -1988,6 +1993,7 @@ struct FtPlan {
     // forward lists decoded once per batch (ft_fwd_decode_kernel, read by ft_fwd_lds<PRE>)
     bool predec;
     size_t off_foffs, off_fblk;
+    int fwd_G, fwd_epw;  // grid of the ungrouped LDS forward: workgroups per row tile, entries per workgroup
 };
 
 int ft_validate(const bt_ft_desc *d, const char *who) {
@@ -2115,6 +2121,12 @@ int ft_plan(const bt_ft_desc *d, FtPlan *p) {
     if (p->predec) {
         p->off_foffs = o, o += bt_align((size_t)E * 32 * sizeof(uint32_t));
         p->off_fblk = o, o += bt_align((size_t)bt_div_up(E, 8));
+    }
+    {
+        int G = std::max(1, 256 / std::max(1, p->ntiles));
+        long long epw = (E + G - 1) / G;
+        epw = (epw + 127) / 128 * 128;  // whole passes of 16 waves x 8 entries
+        p->fwd_G = (int)((E + epw - 1) / epw), p->fwd_epw = (int)epw;
     }
     p->total = o;
     return BT_OK;
@@ -2280,12 +2292,8 @@ int ft_forward_lds_launch(hipStream_t s, const bt_ft_desc *d, const FtPlan &p, c
                           const int32_t *i0, const int32_t *i1, float *out, float *saved, const FtHeadSink *head,
                           char *ws = nullptr, bool pre_decoded = false) {
     pre_decoded = pre_decoded && p.predec && head && ws;
-    const long long E = (long long)d->n_inputs * d->batch;
-    int G = 256 / p.ntiles;
-    if (G < 1) G = 1;
-    long long epw = (E + G - 1) / G;
-    epw = (epw + 127) / 128 * 128;  // whole passes of 16 waves x 8 entries
-    G = (int)((E + epw - 1) / epw);
+    const int G = p.fwd_G;
+    const long long epw = p.fwd_epw;
     const int nround = (d->nnz + 31) / 32;
     const bool al4 = d->nnz % 4 == 0 && (reinterpret_cast<uintptr_t>(i0) & 15) == 0 &&
                      (reinterpret_cast<uintptr_t>(i1) & 15) == 0;
@@ -2403,15 +2411,16 @@ int bt_internal_ft_build_groups(void *stream, const bt_ft_desc *d, const int32_t
     const int32_t *i0 = idx[0], *i1 = d->n_inputs > 1 ? idx[1] : idx[0];
     const int E = d->n_inputs * d->batch;
     if (p.predec) {
+        lds_u4_t *foffs = reinterpret_cast<lds_u4_t *>(ws + p.off_foffs);
+        uint8_t *fblk = reinterpret_cast<uint8_t *>(ws + p.off_fblk);
+        const dim3 dgrid(bt_div_up((long long)E * 8, 256));
         if (done) bt_attach_stop_event(BTK_FT_INDEX, done);
         if (g_ft_env.decode_parity)
-            BT_LAUNCH(BTK_FT_INDEX, s, ft_fwd_decode_kernel<true>, dim3(bt_div_up((long long)E * 8, 256)), dim3(256), 0, i0, i1,
-                      d->batch, d->nnz, d->cols, E, reinterpret_cast<lds_u4_t *>(ws + p.off_foffs),
-                      reinterpret_cast<uint8_t *>(ws + p.off_fblk));
+            BT_LAUNCH(BTK_FT_INDEX, s, ft_fwd_decode_kernel<true>, dgrid, dim3(256), 0, i0, i1, d->batch, d->nnz, d->cols, E, foffs,
+                      fblk);
         else
-            BT_LAUNCH(BTK_FT_INDEX, s, ft_fwd_decode_kernel<false>, dim3(bt_div_up((long long)E * 8, 256)), dim3(256), 0, i0, i1,
-                      d->batch, d->nnz, d->cols, E, reinterpret_cast<lds_u4_t *>(ws + p.off_foffs),
-                      reinterpret_cast<uint8_t *>(ws + p.off_fblk));
+            BT_LAUNCH(BTK_FT_INDEX, s, ft_fwd_decode_kernel<false>, dgrid, dim3(256), 0, i0, i1, d->batch, d->nnz, d->cols, E, foffs,
+                      fblk);
         BT_LAUNCH_CHECK();
         return BT_OK;
     }
