@@ -19,7 +19,7 @@ ap.add_argument("--occupancy", default="full")
 ap.add_argument("--net", default="cfg2")
 ap.add_argument("--names", default="top,barrier1,write+fixup,barrier2,stage_first,reduce,rows+stage_last")
 a = ap.parse_args()
-args = argparse.Namespace(upload="records", spinup_ms=50.0, no_hints=False, no_profile=True)
+args = argparse.Namespace(upload="records", spinup_ms=50.0, no_hints=False, no_profile=True, graphs="off")
 import torch  # noqa: E402
 from bullet_amd import lib  # noqa: E402
 
